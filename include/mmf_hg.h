@@ -1,0 +1,190 @@
+/*
+ * mmf_hg.h — C ABI of libmmf_hg.so: MI355X (gfx950) hypergraph-construction hot path.
+ *
+ * The reference (zz9tf/multimodal-fusion) is pure Python and has no FFI of its own; its
+ * boundary for this path is the set of Python functions re-exported by
+ *   build_hypergraph/__init__.py:5-46  and  hypergraph/build_hypergraph/__init__.py:5-19.
+ * Each entry point below names the reference code it replaces (paths relative to the
+ * reference root).  The Python mirror of those functions lives in
+ * multimodal-fusion_amd/build_hypergraph/ and binds this ABI with ctypes
+ * (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - All pointers are raw DEVICE addresses (tensor.data_ptr()) unless a parameter says host.
+ *   - Matrices are row-major and contiguous.  Indices are int64, scores are f32.
+ *   - Every call enqueues on `hip_stream` (a hipStream_t, NULL = default stream) of device
+ *     `device_id`.  Calls are asynchronous w.r.t. the host except where noted.
+ *   - Return value: MMF_OK (0) or a negative MMF_E_* code.  Never throws, never aborts;
+ *     mmf_last_error() gives the message of the calling thread's last failure.
+ *   - There is NO CPU implementation behind this ABI.  device_id < 0 is rejected with
+ *     MMF_E_UNSUPPORTED: the CPU restatement lives in oracle/ and is test infrastructure only.
+ *
+ * Canonical arithmetic (what "bit-exact" means; DESIGN.md §3 has the full statement)
+ *   chain(a,b)   = acc = +0.0f; for k = 0..d-1: acc = fmaf(a[k], b[k], acc)      (k ascending)
+ *   n_i          = chain(x_i, x_i);   dot_ij = chain(x_i, y_j)
+ *   sq_ij        = (n_i + n_j) - 2*dot_ij           (similarity_kernel.py:49, same op order)
+ *   MMF_DOT      key = val = dot_ij
+ *   MMF_COSINE   key = val = dot_ij / (max(sqrtf(n_i),1e-8f) * max(sqrtf(n_j),1e-8f))
+ *   MMF_NEG_SQ_L2 key = val = -sq_ij
+ *   MMF_RBF      key = (-lambda)*sq_ij, val = expf(key)  (similarity_kernel.py:52)
+ *   Ranking: key descending, then GLOBAL column id ascending; self (global col id == global
+ *   row id) dropped by identity when exclude_self != 0.
+ *   bf16 / f16 inputs are upcast to f32 exactly and then follow the same definition.
+ */
+#ifndef MMF_HG_H
+#define MMF_HG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMF_ABI_VERSION 1
+
+/* return codes */
+#define MMF_OK             0
+#define MMF_E_INVALID     (-1)  /* bad shape / argument          -> Python ValueError   */
+#define MMF_E_UNSUPPORTED (-2)  /* valid but not implemented     -> Python RuntimeError */
+#define MMF_E_HIP         (-3)  /* HIP runtime failure           -> Python RuntimeError */
+#define MMF_E_NOMEM       (-4)  /* workspace allocation failed   -> Python RuntimeError */
+#define MMF_E_INTERNAL    (-5)  /* invariant broken (a bug)      -> Python RuntimeError */
+
+/* metric */
+#define MMF_DOT        0
+#define MMF_COSINE     1
+#define MMF_NEG_SQ_L2  2
+#define MMF_RBF        3
+#define MMF_RBF_DIRECT 4  /* dense only: exp(-lambda * sum_k (a_k-b_k)^2), preprocess_hypergraph.py:254-256 */
+
+/* element type of X / Y */
+#define MMF_F32  0
+#define MMF_BF16 1
+#define MMF_F16  2
+
+/* candidate-generation precision for mmf_simtopk_ex.  The RESULT is identical in every mode
+ * (final keys are always the canonical f32 chain); the mode only picks which MFMA pipe scans
+ * the N x M pairs. */
+#define MMF_PREC_AUTO  0  /* FAST when the shape is supported by the bf16 kernel, else EXACT */
+#define MMF_PREC_EXACT 1  /* v_mfma_f32_32x32x2_f32 scan, canonical keys in-kernel           */
+#define MMF_PREC_FAST  2  /* bf16/f16 MFMA scan with a proven error margin + exact f32 re-rank */
+
+int         mmf_version(void);
+const char* mmf_last_error(void);
+
+/*
+ * Fused similarity + per-row top-k; the N x M matrix never reaches HBM.
+ * Replaces: torch.mm + elementwise passes (build_hypergraph/similarity_kernel.py:43-52),
+ *           sklearn NearestNeighbors(k+1).kneighbors + "drop column 0"
+ *           (build_hypergraph/preprocess_hypergraph.py:379-388) when metric = MMF_NEG_SQ_L2,
+ *           and the per-row Python loop of compute_wsi_tma_similarity (:250-257) when only the
+ *           best matches per row are wanted.
+ * X:[n,d], Y:[m,d] (Y == NULL -> Y = X, m = n).  in_dtype: MMF_F32 / MMF_BF16 / MMF_F16.
+ * exclude_self: drop the column whose global id (col_offset + j) equals row_offset + i.
+ * out_idx:[n,k] int64 GLOBAL column ids, out_val:[n,k] f32; both sorted (key desc, id asc).
+ * Errors: k < 1, k > (number of admissible columns), d < 1, n < 0, lambda <= 0 for MMF_RBF
+ *         -> MMF_E_INVALID.   n == 0 is a no-op.
+ * Host-synchronous once per call (reads back one fallback counter).
+ */
+int mmf_simtopk(const void* X, int64_t n, const void* Y, int64_t m, int64_t d,
+                int in_dtype, int metric, float lambda, int k, int exclude_self,
+                int64_t row_offset, int64_t col_offset,
+                int64_t* out_idx, float* out_val,
+                int device_id, void* hip_stream);
+
+/* Same, with the knobs the bench and the tests need. */
+typedef struct mmf_simtopk_opts {
+  int      precision;      /* MMF_PREC_*                                                        */
+  int      profile;        /* 1: bracket the scan kernel with HIP events on hip_stream           */
+  int      col_splits;     /* 0 = auto; >0 forces the number of column ranges per row block      */
+  int      reserved0;
+} mmf_simtopk_opts;
+
+typedef struct mmf_simtopk_stats {
+  float    scan_ms;        /* duration of the scan (candidate) kernel, valid when profile = 1    */
+  float    prep_ms;        /* norms / bf16 conversion kernels                                    */
+  float    rerank_ms;      /* exact re-rank + select kernel                                      */
+  float    fallback_ms;    /* exact rescans of overflowed rows (0 when none)                     */
+  int64_t  candidates;     /* total candidates handed to the re-rank                            */
+  int64_t  fallback_rows;  /* rows whose candidate list overflowed and were rescanned exactly    */
+  int      precision_used; /* MMF_PREC_EXACT or MMF_PREC_FAST                                    */
+  int      col_splits;     /* column ranges per row block actually used                         */
+  int      scan_grid;      /* workgroups launched by the scan kernel                             */
+  int      reserved0;
+} mmf_simtopk_stats;
+
+int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d,
+                   int in_dtype, int metric, float lambda, int k, int exclude_self,
+                   int64_t row_offset, int64_t col_offset,
+                   int64_t* out_idx, float* out_val,
+                   const mmf_simtopk_opts* opts /* NULL = defaults */,
+                   mmf_simtopk_stats* stats /* host, may be NULL */,
+                   int device_id, void* hip_stream);
+
+/*
+ * Merge two sorted [n,k] partial results into one (column-panel streaming, cross-shard merges).
+ * Order and tie-break as above; an id present in both inputs is kept once.  ids < 0 are padding.
+ * No reference counterpart (the reference is single-device).
+ */
+int mmf_topk_merge(const int64_t* ia, const float* va, const int64_t* ib, const float* vb,
+                   int64_t n, int k, int64_t* io, float* vo, int device_id, void* hip_stream);
+
+/*
+ * Edge weights for an explicit edge list: w_e = max(0, cos(x_i, x_j)) with the canonical cosine.
+ * Replaces: the per-edge F.cosine_similarity(...).item() loop,
+ *           build_hypergraph/preprocess_hypergraph.py:414-420.
+ * edge_index:[2,E] int64 (row 0 = i, row 1 = j), out_w:[E] f32.  ids outside [0,n) -> MMF_E_INVALID
+ * is NOT checked on device; the Python mirror validates.
+ */
+int mmf_edge_cosine(const void* X, int64_t n, int64_t d, int in_dtype,
+                    const int64_t* edge_index, int64_t E, float* out_w,
+                    int device_id, void* hip_stream);
+
+/*
+ * Dense [n,m] f32 similarity for the small-N reference signatures.
+ * Replaces: compute_morphological_similarity / compute_spatial_similarity
+ *           (build_hypergraph/similarity_kernel.py:17-54, 57-86; same code in
+ *           hypergraph/build_hypergraph/similarity_kernel.py) with metric = MMF_RBF, and
+ *           compute_wsi_tma_similarity (build_hypergraph/preprocess_hypergraph.py:248-257) with
+ *           metric = MMF_RBF_DIRECT.
+ * Y == NULL -> Y = X.  out:[n,m] f32.  For MMF_RBF any lambda is accepted (as the reference).
+ */
+int mmf_sim_dense(const void* X, int64_t n, const void* Y, int64_t m, int64_t d,
+                  int in_dtype, int metric, float lambda, float* out,
+                  int device_id, void* hip_stream);
+
+/*
+ * Dense combined similarity K = K_h * K_g in one pass (no K_h / K_g temporaries).
+ * Replaces: compute_combined_similarity, build_hypergraph/similarity_kernel.py:88-124.
+ * F:[n,d] features, P:[n,dp] positions (dp = 2 or 3, any dp >= 1 accepted), both f32.
+ * out:[n,n] f32 = exp(-lambda_h*sq_h) * exp(-lambda_g*sq_g), each factor rounded to f32 first
+ * (similarity_kernel.py:122).
+ */
+int mmf_sim_dense_combined(const float* F, const float* P, int64_t n, int64_t d, int64_t dp,
+                           float lambda_h, float lambda_g, float* out,
+                           int device_id, void* hip_stream);
+
+/*
+ * Threshold edge builder over a dense [n,n] similarity already in HBM.
+ * Replaces: build_weighted_hypergraph's median + double loop,
+ *           build_hypergraph/similarity_kernel.py:183-202 (row-major order, self-loops kept).
+ *   mmf_offdiag_lower_median: lower median (torch.median semantics) of the n(n-1) off-diagonal
+ *                             entries; result written to *out_median (device f32).
+ *   mmf_threshold_edges:      keep (i,j) with K[i,j] >= threshold, row-major; writes at most
+ *                             `capacity` edges, always writes the true count to *out_count
+ *                             (device int64).  edge_index:[2,capacity] int64, edge_w:[capacity].
+ */
+int mmf_offdiag_lower_median(const float* K, int64_t n, float* out_median,
+                             int device_id, void* hip_stream);
+int mmf_threshold_edges(const float* K, int64_t n, float threshold,
+                        int64_t* edge_index, float* edge_w, int64_t capacity,
+                        int64_t* out_count, int device_id, void* hip_stream);
+
+/* Release the library's cached per-device workspaces (they are grow-only otherwise). */
+int mmf_release_workspaces(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMF_HG_H */
