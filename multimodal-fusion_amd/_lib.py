@@ -1,0 +1,78 @@
+"""ctypes binding of libmmf_hg.so (include/mmf_hg.h).  Fails loudly when the library is missing:
+there is no CPU fallback anywhere in this package."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libmmf_hg.so")
+
+MMF_OK, MMF_E_INVALID, MMF_E_UNSUPPORTED, MMF_E_HIP, MMF_E_NOMEM, MMF_E_INTERNAL = 0, -1, -2, -3, -4, -5
+DOT, COSINE, NEG_SQ_L2, RBF, RBF_DIRECT = 0, 1, 2, 3, 4
+METRICS = {"dot": DOT, "cosine": COSINE, "neg_sq_l2": NEG_SQ_L2, "rbf": RBF, "rbf_direct": RBF_DIRECT}
+F32, BF16, F16 = 0, 1, 2
+PRECISIONS = {"auto": 0, "exact": 1, "fast": 2}
+
+
+class SimtopkOpts(ctypes.Structure):
+    _fields_ = [("precision", ctypes.c_int), ("profile", ctypes.c_int), ("col_splits", ctypes.c_int),
+                ("reserved0", ctypes.c_int)]
+
+
+class SimtopkStats(ctypes.Structure):
+    _fields_ = [("scan_ms", ctypes.c_float), ("prep_ms", ctypes.c_float), ("rerank_ms", ctypes.c_float),
+                ("fallback_ms", ctypes.c_float), ("candidates", ctypes.c_int64), ("fallback_rows", ctypes.c_int64),
+                ("precision_used", ctypes.c_int), ("col_splits", ctypes.c_int), ("scan_grid", ctypes.c_int),
+                ("reserved0", ctypes.c_int)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_ if not f.startswith("reserved")}
+
+
+_lib = None
+
+EXPORTS = ["mmf_version", "mmf_last_error", "mmf_simtopk", "mmf_simtopk_ex", "mmf_topk_merge", "mmf_edge_cosine",
+           "mmf_sim_dense", "mmf_sim_dense_combined", "mmf_offdiag_lower_median", "mmf_threshold_edges",
+           "mmf_release_workspaces"]
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            f"{SO_PATH} is missing: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or python multimodal-fusion_amd/csrc/build.py).  This package has no CPU fallback.")
+    L = ctypes.CDLL(SO_PATH)
+    vp, i64, ci, f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+    L.mmf_version.restype = ci
+    L.mmf_last_error.restype = ctypes.c_char_p
+    L.mmf_simtopk.argtypes = [vp, i64, vp, i64, i64, ci, ci, f32, ci, ci, i64, i64, vp, vp, ci, vp]
+    L.mmf_simtopk_ex.argtypes = [vp, i64, vp, i64, i64, ci, ci, f32, ci, ci, i64, i64, vp, vp,
+                                 ctypes.POINTER(SimtopkOpts), ctypes.POINTER(SimtopkStats), ci, vp]
+    L.mmf_topk_merge.argtypes = [vp, vp, vp, vp, i64, ci, vp, vp, ci, vp]
+    L.mmf_edge_cosine.argtypes = [vp, i64, i64, ci, vp, i64, vp, ci, vp]
+    L.mmf_sim_dense.argtypes = [vp, i64, vp, i64, i64, ci, ci, f32, vp, ci, vp]
+    L.mmf_sim_dense_combined.argtypes = [vp, vp, i64, i64, i64, f32, f32, vp, ci, vp]
+    L.mmf_offdiag_lower_median.argtypes = [vp, i64, vp, ci, vp]
+    L.mmf_threshold_edges.argtypes = [vp, i64, f32, vp, vp, i64, vp, ci, vp]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if name not in ("mmf_last_error",):
+            fn.restype = ci
+    L.mmf_last_error.restype = ctypes.c_char_p
+    if L.mmf_version() != 1:
+        raise RuntimeError(f"libmmf_hg.so ABI version {L.mmf_version()} != 1")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc == MMF_OK:
+        return
+    msg = lib().mmf_last_error().decode("utf-8", "replace")
+    if rc == MMF_E_INVALID:
+        raise ValueError(f"{what}: {msg}")
+    raise RuntimeError(f"{what}: {msg} (code {rc})")

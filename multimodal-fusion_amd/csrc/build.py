@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Build libmmf_hg.so (gfx950) in-tree with hipcc: one object per .hip, then one shared library.
+
+    python multimodal-fusion_amd/csrc/build.py [--force] [-j N]
+
+-ffp-contract=off is part of the numerics contract (include/mmf_hg.h): every fused multiply-add in
+the kernels is an explicit fmaf.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+ROOT = os.path.dirname(PKG)
+OUT = os.path.join(PKG, "libmmf_hg.so")
+OBJ = os.path.join(HERE, "_obj")
+SOURCES = ["mmf_api.hip", "mmf_prep.hip", "mmf_scan_f32.hip", "mmf_scan_bf16.hip", "mmf_select.hip", "mmf_edges.hip"]
+HEADERS = ["mmf_dev.h", "mmf_host.h", os.path.join(ROOT, "include", "mmf_hg.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-std=c++17", "-fno-gpu-rdc",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force: bool = False, jobs: int = 6, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS]
+    todo = []
+    objs = []
+    for src in SOURCES:
+        sp = os.path.join(HERE, src)
+        op = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(op)
+        if force or not _newer(op, [sp, *hdrs, os.path.abspath(__file__)]):
+            todo.append((sp, op))
+
+    def cc(job):
+        sp, op = job
+        cmd = [HIPCC, *FLAGS, "-c", sp, "-o", op]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {sp}:\n{r.stdout}\n{r.stderr}")
+        if r.stderr.strip() and verbose:
+            print(r.stderr)
+        return op
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
+            list(ex.map(cc, todo))
+    if todo or force or not _newer(OUT, objs):
+        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", *objs, "-o", OUT + ".tmp"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        os.replace(OUT + ".tmp", OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    j = 6
+    if "-j" in sys.argv:
+        j = int(sys.argv[sys.argv.index("-j") + 1])
+    print(build(force="--force" in sys.argv, jobs=j, verbose=True))

@@ -1,0 +1,351 @@
+// mmf_api.hip — the C ABI of include/mmf_hg.h.  Host code only: validation, workspace layout,
+// kernel sequencing.  No CPU compute path exists here (device_id < 0 is an error).
+#include <stdarg.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+#include "mmf_host.h"
+
+namespace mmf {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+struct WsEntry { char* base = nullptr; size_t cap = 0; };
+static std::mutex g_ws_mu;
+static std::map<std::pair<int, hipStream_t>, WsEntry> g_ws;
+
+int get_workspace(int device, hipStream_t stream, size_t bytes, Workspace* out) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  WsEntry& e = g_ws[std::make_pair(device, stream)];
+  if (e.cap < bytes) {
+    if (e.base) {
+      MMF_HIP(hipStreamSynchronize(stream));
+      MMF_HIP(hipFree(e.base));
+      e.base = nullptr;
+      e.cap = 0;
+    }
+    size_t want = bytes + (bytes >> 3) + (1u << 20);
+    void* p = nullptr;
+    hipError_t rc = hipMalloc(&p, want);
+    if (rc != hipSuccess) {
+      set_error("workspace allocation of %zu bytes failed: %s", want, hipGetErrorString(rc));
+      return MMF_E_NOMEM;
+    }
+    e.base = static_cast<char*>(p);
+    e.cap = want;
+  }
+  out->base = e.base;
+  out->cap = e.cap;
+  out->off = 0;
+  return MMF_OK;
+}
+
+int launch_edge_cosine_impl(const void* X, int64_t d, int dtype, const float* nrm, const int64_t* ei, int64_t E,
+                            float* out, hipStream_t s);
+
+// mmf_scan_bf16.hip (fast path); returns 0 capacity when the shape is not supported
+int scan_bf16_supported(int64_t d, int kk, int dtype);
+
+static int check_common(const void* X, int64_t n, int64_t m, int64_t d, int in_dtype, int device_id) {
+  if (device_id < 0) {
+    set_error("device_id %d: this library has no CPU path (the CPU restatement is oracle/, tests only)", device_id);
+    return MMF_E_UNSUPPORTED;
+  }
+  if (n < 0 || m < 0 || d < 1) { set_error("bad shape n=%lld m=%lld d=%lld", (long long)n, (long long)m, (long long)d); return MMF_E_INVALID; }
+  if (in_dtype != MMF_F32 && in_dtype != MMF_BF16 && in_dtype != MMF_F16) { set_error("bad in_dtype %d", in_dtype); return MMF_E_INVALID; }
+  if (n > 0 && !X) { set_error("X is NULL"); return MMF_E_INVALID; }
+  if (n >= (int64_t)1 << 31 || m >= (int64_t)1 << 31) { set_error("n and m must be < 2^31"); return MMF_E_UNSUPPORTED; }
+  return MMF_OK;
+}
+
+struct EventTimer {
+  hipEvent_t a = nullptr, b = nullptr;
+  bool on = false;
+  int start(bool enable, hipStream_t s) {
+    on = enable;
+    if (!on) return MMF_OK;
+    MMF_HIP(hipEventCreate(&a));
+    MMF_HIP(hipEventCreate(&b));
+    MMF_HIP(hipEventRecord(a, s));
+    return MMF_OK;
+  }
+  int stop(hipStream_t s) {
+    if (!on) return MMF_OK;
+    MMF_HIP(hipEventRecord(b, s));
+    return MMF_OK;
+  }
+  float ms() {
+    float t = 0.f;
+    if (on && a && b && hipEventSynchronize(b) == hipSuccess) (void)hipEventElapsedTime(&t, a, b);
+    return t;
+  }
+  ~EventTimer() {
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+  }
+};
+
+static int pick_splits(int64_t row_blocks, int64_t col_tiles, int lists_cap, int cap, int forced) {
+  int64_t s = forced > 0 ? forced : (768 + row_blocks - 1) / row_blocks;
+  if (s > col_tiles) s = col_tiles;
+  const int64_t max_lists = 1024 / cap;  // select kernel capacity per row
+  if (2 * s > max_lists) s = max_lists / 2;
+  if (s < 1) s = 1;
+  (void)lists_cap;
+  return (int)s;
+}
+
+}  // namespace mmf
+
+using namespace mmf;
+
+extern "C" {
+
+int mmf_version(void) { return MMF_ABI_VERSION; }
+const char* mmf_last_error(void) { return g_err; }
+
+int mmf_release_workspaces(void) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  for (auto& kv : g_ws) {
+    if (kv.second.base) {
+      int prev = -1;
+      (void)hipGetDevice(&prev);
+      (void)hipSetDevice(kv.first.first);
+      (void)hipDeviceSynchronize();
+      (void)hipFree(kv.second.base);
+      if (prev >= 0) (void)hipSetDevice(prev);
+    }
+  }
+  g_ws.clear();
+  return MMF_OK;
+}
+
+int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d, int in_dtype, int metric,
+                   float lambda, int k, int exclude_self, int64_t row_offset, int64_t col_offset, int64_t* out_idx,
+                   float* out_val, const mmf_simtopk_opts* opts, mmf_simtopk_stats* stats, int device_id,
+                   void* hip_stream) {
+  if (!Y) { Y = X; m = n; }
+  MMF_TRY(check_common(X, n, m, d, in_dtype, device_id));
+  if (metric < MMF_DOT || metric > MMF_RBF) { set_error("simtopk: bad metric %d", metric); return MMF_E_INVALID; }
+  if (metric == MMF_RBF && !(lambda > 0.0f)) { set_error("simtopk: MMF_RBF needs lambda > 0 (got %g)", lambda); return MMF_E_INVALID; }
+  if (k < 1) { set_error("simtopk: k must be >= 1 (got %d)", k); return MMF_E_INVALID; }
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (n == 0) return MMF_OK;
+  if (!out_idx || !out_val) { set_error("simtopk: NULL output"); return MMF_E_INVALID; }
+  // admissible columns: m, minus one for rows whose own id lies in the column range
+  {
+    const int64_t lo = col_offset, hi = col_offset + m;
+    const int64_t r0 = row_offset, r1 = row_offset + n;  // any overlap -> some row loses one column
+    const bool overlap = exclude_self && (r0 < hi) && (r1 > lo);
+    const int64_t adm = m - (overlap ? 1 : 0);
+    if (k > adm) {
+      set_error("simtopk: k = %d exceeds the %lld admissible columns (m = %lld%s)", k, (long long)adm, (long long)m,
+                overlap ? ", self excluded" : "");
+      return MMF_E_INVALID;
+    }
+  }
+  const int kk = k + (exclude_self ? 1 : 0);
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+
+  int precision = opts ? opts->precision : MMF_PREC_AUTO;
+  const bool profile = opts && opts->profile;
+  const int forced_splits = opts ? opts->col_splits : 0;
+  if (precision == MMF_PREC_AUTO) precision = scan_bf16_supported(d, kk, in_dtype) ? MMF_PREC_FAST : MMF_PREC_EXACT;
+  if (precision == MMF_PREC_FAST && !scan_bf16_supported(d, kk, in_dtype)) {
+    set_error("simtopk: MMF_PREC_FAST does not support d = %lld, k = %d (use AUTO or EXACT)", (long long)d, k);
+    return MMF_E_UNSUPPORTED;
+  }
+  const int cap = scan_f32_cap(kk);
+  if (cap == 0) { set_error("simtopk: k = %d is above the supported maximum (27 with self excluded, 28 without)", k); return MMF_E_UNSUPPORTED; }
+
+  if (precision == MMF_PREC_FAST) {
+    set_error("simtopk: fast path not built");
+    return MMF_E_UNSUPPORTED;
+  }
+
+  // ---- exact path ------------------------------------------------------------------------------
+  const int64_t row_blocks = (n + 127) / 128, col_tiles = (m + 127) / 128;
+  const int splits = pick_splits(row_blocks, col_tiles, 0, cap, forced_splits);
+  const int lists = 2 * splits;
+  const bool same = (Y == X) && (m == n);
+  size_t need = ws_bytes(n, 4) + (same ? 0 : ws_bytes(m, 4)) + ws_bytes((size_t)n * lists, 4) +
+                ws_bytes((size_t)n * lists * cap, 4) + ws_bytes(n, 4) + ws_bytes(n, 4) + ws_bytes(4, 4) + ws_bytes(256, 4);
+  Workspace ws;
+  MMF_TRY(get_workspace(device_id, s, need, &ws));
+  float* rx = ws.take<float>(n);
+  float* cy = same ? rx : ws.take<float>(m);
+  CandLists L;
+  L.cnt = ws.take<uint32_t>((size_t)n * lists);
+  L.ids = ws.take<uint32_t>((size_t)n * lists * cap);
+  L.overflow = ws.take<uint32_t>(n);
+  L.lists = lists;
+  L.cap = cap;
+  int32_t* fail_rows = ws.take<int32_t>(n);
+  uint32_t* fail_count = ws.take<uint32_t>(4);
+  uint32_t* cand_total = ws.take<uint32_t>(256);
+  MMF_HIP(hipMemsetAsync(L.overflow, 0, (size_t)n * 4, s));
+  MMF_HIP(hipMemsetAsync(fail_count, 0, 16, s));
+  MMF_HIP(hipMemsetAsync(cand_total, 0, 1024, s));
+
+  EventTimer t_prep, t_scan, t_sel;
+  MMF_TRY(t_prep.start(profile, s));
+  MMF_TRY(launch_row_scalars(X, n, d, in_dtype, metric, rx, s));
+  if (!same) MMF_TRY(launch_row_scalars(Y, m, d, in_dtype, metric, cy, s));
+  MMF_TRY(t_prep.stop(s));
+
+  ScanProblem sp{};
+  sp.X = X; sp.n = n; sp.Y = Y; sp.m = m; sp.d = d; sp.dtype = in_dtype; sp.metric = metric; sp.lambda = lambda;
+  sp.kk = kk; sp.rx = rx; sp.cy = cy; sp.row_ids = nullptr; sp.n_rows = n; sp.col_splits = splits;
+  int grid = 0;
+  MMF_TRY(t_scan.start(profile, s));
+  MMF_TRY(launch_scan_f32(sp, L, s, &grid));
+  MMF_TRY(t_scan.stop(s));
+
+  SelectProblem q{};
+  q.X = X; q.n = n; q.Y = Y; q.m = m; q.d = d; q.dtype = in_dtype; q.metric = metric; q.lambda = lambda;
+  q.k = k; q.exclude_self = exclude_self; q.row_offset = row_offset; q.col_offset = col_offset;
+  q.rx = rx; q.cy = cy; q.row_ids = nullptr; q.n_rows = n; q.out_idx = out_idx; q.out_val = out_val;
+  q.fail_rows = fail_rows; q.fail_count = fail_count; q.cand_total = stats ? cand_total : nullptr;
+  MMF_TRY(t_sel.start(profile, s));
+  MMF_TRY(launch_select(q, L, s));
+  MMF_TRY(t_sel.stop(s));
+
+  uint32_t h_fail = 0;
+  MMF_HIP(hipMemcpyAsync(&h_fail, fail_count, 4, hipMemcpyDeviceToHost, s));
+  std::vector<uint32_t> h_tot(stats ? 256 : 0);
+  if (stats) MMF_HIP(hipMemcpyAsync(h_tot.data(), cand_total, 1024, hipMemcpyDeviceToHost, s));
+  MMF_HIP(hipStreamSynchronize(s));
+  if (h_fail != 0) {
+    set_error("simtopk: %u rows failed in the exact scan (internal invariant)", h_fail);
+    return MMF_E_INTERNAL;
+  }
+  if (stats) {
+    stats->precision_used = MMF_PREC_EXACT;
+    stats->col_splits = splits;
+    stats->scan_grid = grid;
+    stats->prep_ms = t_prep.ms();
+    stats->scan_ms = t_scan.ms();
+    stats->rerank_ms = t_sel.ms();
+    int64_t tot = 0;
+    for (uint32_t v : h_tot) tot += v;
+    stats->candidates = tot;
+  }
+  return MMF_OK;
+}
+
+int mmf_simtopk(const void* X, int64_t n, const void* Y, int64_t m, int64_t d, int in_dtype, int metric, float lambda,
+                int k, int exclude_self, int64_t row_offset, int64_t col_offset, int64_t* out_idx, float* out_val,
+                int device_id, void* hip_stream) {
+  return mmf_simtopk_ex(X, n, Y, m, d, in_dtype, metric, lambda, k, exclude_self, row_offset, col_offset, out_idx,
+                        out_val, nullptr, nullptr, device_id, hip_stream);
+}
+
+int mmf_topk_merge(const int64_t* ia, const float* va, const int64_t* ib, const float* vb, int64_t n, int k,
+                   int64_t* io, float* vo, int device_id, void* hip_stream) {
+  if (device_id < 0) { set_error("topk_merge: no CPU path"); return MMF_E_UNSUPPORTED; }
+  if (n < 0 || k < 1) { set_error("topk_merge: bad n/k"); return MMF_E_INVALID; }
+  if (n == 0) return MMF_OK;
+  if (!ia || !va || !ib || !vb || !io || !vo) { set_error("topk_merge: NULL pointer"); return MMF_E_INVALID; }
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  return launch_topk_merge(ia, va, ib, vb, n, k, io, vo, static_cast<hipStream_t>(hip_stream));
+}
+
+int mmf_edge_cosine(const void* X, int64_t n, int64_t d, int in_dtype, const int64_t* edge_index, int64_t E,
+                    float* out_w, int device_id, void* hip_stream) {
+  MMF_TRY(check_common(X, n, n, d, in_dtype, device_id));
+  if (E < 0) { set_error("edge_cosine: E < 0"); return MMF_E_INVALID; }
+  if (E == 0) return MMF_OK;
+  if (!edge_index || !out_w) { set_error("edge_cosine: NULL pointer"); return MMF_E_INVALID; }
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  Workspace ws;
+  MMF_TRY(get_workspace(device_id, s, ws_bytes(n, 4), &ws));
+  float* nrm = ws.take<float>(n);
+  MMF_TRY(launch_row_scalars(X, n, d, in_dtype, MMF_COSINE, nrm, s));
+  return launch_edge_cosine_impl(X, d, in_dtype, nrm, edge_index, E, out_w, s);
+}
+
+int mmf_sim_dense(const void* X, int64_t n, const void* Y, int64_t m, int64_t d, int in_dtype, int metric,
+                  float lambda, float* out, int device_id, void* hip_stream) {
+  if (!Y) { Y = X; m = n; }
+  MMF_TRY(check_common(X, n, m, d, in_dtype, device_id));
+  if (metric < MMF_DOT || metric > MMF_RBF_DIRECT) { set_error("sim_dense: bad metric %d", metric); return MMF_E_INVALID; }
+  if (n == 0 || m == 0) return MMF_OK;
+  if (!out) { set_error("sim_dense: NULL output"); return MMF_E_INVALID; }
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  const bool same = (Y == X) && (m == n);
+  float *rx = nullptr, *cy = nullptr;
+  if (metric != MMF_RBF_DIRECT) {
+    Workspace ws;
+    MMF_TRY(get_workspace(device_id, s, ws_bytes(n, 4) + ws_bytes(m, 4), &ws));
+    rx = ws.take<float>(n);
+    cy = same ? rx : ws.take<float>(m);
+    MMF_TRY(launch_row_scalars(X, n, d, in_dtype, metric, rx, s));
+    if (!same) MMF_TRY(launch_row_scalars(Y, m, d, in_dtype, metric, cy, s));
+  }
+  return launch_sim_dense(X, n, Y, m, d, in_dtype, metric, lambda, rx, cy, out, s);
+}
+
+int mmf_sim_dense_combined(const float* F, const float* P, int64_t n, int64_t d, int64_t dp, float lambda_h,
+                           float lambda_g, float* out, int device_id, void* hip_stream) {
+  MMF_TRY(check_common(F, n, n, d, MMF_F32, device_id));
+  if (dp < 1) { set_error("sim_dense_combined: dp < 1"); return MMF_E_INVALID; }
+  if (n == 0) return MMF_OK;
+  if (!P || !out) { set_error("sim_dense_combined: NULL pointer"); return MMF_E_INVALID; }
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  Workspace ws;
+  MMF_TRY(get_workspace(device_id, s, ws_bytes(n, 4), &ws));
+  float* nf = ws.take<float>(n);
+  MMF_TRY(launch_row_scalars(F, n, d, MMF_F32, MMF_RBF, nf, s));
+  return launch_sim_dense_combined(F, P, n, d, dp, lambda_h, lambda_g, nf, out, s);
+}
+
+int mmf_offdiag_lower_median(const float* K, int64_t n, float* out_median, int device_id, void* hip_stream) {
+  if (device_id < 0) { set_error("offdiag_lower_median: no CPU path"); return MMF_E_UNSUPPORTED; }
+  if (n < 2) { set_error("offdiag_lower_median: need n >= 2 (got %lld)", (long long)n); return MMF_E_INVALID; }
+  if (!K || !out_median) { set_error("offdiag_lower_median: NULL pointer"); return MMF_E_INVALID; }
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  Workspace ws;
+  MMF_TRY(get_workspace(device_id, s, ws_bytes(4096, 4), &ws));
+  return launch_offdiag_lower_median(K, n, out_median, ws.take<uint32_t>(4096), s);
+}
+
+int mmf_threshold_edges(const float* K, int64_t n, float threshold, int64_t* edge_index, float* edge_w,
+                        int64_t capacity, int64_t* out_count, int device_id, void* hip_stream) {
+  if (device_id < 0) { set_error("threshold_edges: no CPU path"); return MMF_E_UNSUPPORTED; }
+  if (n < 0 || capacity < 0) { set_error("threshold_edges: bad n/capacity"); return MMF_E_INVALID; }
+  if (!out_count) { set_error("threshold_edges: NULL out_count"); return MMF_E_INVALID; }
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  if (n == 0) { MMF_HIP(hipMemsetAsync(out_count, 0, 8, s)); return MMF_OK; }
+  if (!K || (capacity > 0 && (!edge_index || !edge_w))) { set_error("threshold_edges: NULL pointer"); return MMF_E_INVALID; }
+  const size_t rows_u32 = (size_t)n * 2 + 64;
+  Workspace ws;
+  MMF_TRY(get_workspace(device_id, s, ws_bytes(rows_u32, 8), &ws));
+  return launch_threshold_edges(K, n, threshold, edge_index, edge_w, capacity, out_count,
+                                reinterpret_cast<uint32_t*>(ws.take<uint64_t>(rows_u32)), rows_u32 * 2, s);
+}
+
+}  // extern "C"

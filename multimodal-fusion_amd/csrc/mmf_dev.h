@@ -1,0 +1,284 @@
+// mmf_dev.h — device-side building blocks shared by the gfx950 kernels.
+//
+//  * canonical f32 arithmetic (include/mmf_hg.h): the whole library is compiled with
+//    -ffp-contract=off, every fused multiply-add below is an explicit fmaf;
+//  * lane-private candidate lists in LDS with a wave-wide compaction: the top-k machinery both
+//    scan kernels share.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MMF_DOT 0
+#define MMF_COSINE 1
+#define MMF_NEG_SQ_L2 2
+#define MMF_RBF 3
+#define MMF_RBF_DIRECT 4
+
+namespace mmf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr float kNegInf = -__builtin_huge_valf();
+constexpr float kFltMax = 3.402823466e+38f;
+constexpr uint32_t kNoIdx = 0xffffffffu;
+
+// ---------------------------------------------------------------------------------------------
+// canonical arithmetic
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sq_from(float ni, float nj, float dot) {
+  float s = ni + nj;      // similarity_kernel.py:49  (n_i + n_j) ...
+  float t = 2.0f * dot;   // exact
+  return s - t;           //                           ... - 2*dot
+}
+
+// max(sqrtf(n), 1e-8f): the clamped norm of F.cosine_similarity (preprocess_hypergraph.py:419)
+__device__ __forceinline__ float clamped_norm(float n) {
+  float a = __builtin_sqrtf(n);
+  return (a > 1e-8f) ? a : 1e-8f;
+}
+
+// Ranking key of one pair from its canonical dot.  ri / cj are the per-row / per-column scalars
+// prepared once per call: the canonical squared norm n, or clamped_norm(n) for MMF_COSINE.
+template <int METRIC>
+__device__ __forceinline__ float key_from_dot(float dot, float ri, float cj, float neg_lambda) {
+  if constexpr (METRIC == MMF_DOT) return dot;
+  if constexpr (METRIC == MMF_COSINE) return dot / (ri * cj);
+  if constexpr (METRIC == MMF_NEG_SQ_L2) return -sq_from(ri, cj, dot);
+  return neg_lambda * sq_from(ri, cj, dot);  // MMF_RBF: the exponent
+}
+
+template <int METRIC>
+__device__ __forceinline__ float val_from_key(float key) {
+  if constexpr (METRIC == MMF_RBF) return expf(key);
+  return key;
+}
+
+// element loads with exact upcast to f32
+__device__ __forceinline__ float ld_f32(const float* p, int64_t i) { return p[i]; }
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ float ld_elem(const void* p, int64_t i, int dtype) {
+  if (dtype == 0) return ((const float*)p)[i];
+  if (dtype == 1) return bf16_bits_to_f32(((const uint16_t*)p)[i]);
+  return (float)(((const _Float16*)p)[i]);
+}
+
+// (key desc, id asc); used for every in-kernel ordering decision
+__device__ __forceinline__ bool better(float ka, uint32_t ia, float kb, uint32_t ib) {
+  return (ka > kb) || (ka == kb && ia < ib);
+}
+
+// ---------------------------------------------------------------------------------------------
+// register sorting network (bitonic, fully unrolled): descending by (key, id)
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void sort_desc(float (&k)[N], uint32_t (&id)[N]) {
+#pragma unroll
+  for (int size = 2; size <= N; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int j = i ^ stride;
+        if (j > i) {
+          const bool desc = ((i & size) == 0);
+          const bool sw = desc ? better(k[j], id[j], k[i], id[i]) : better(k[i], id[i], k[j], id[j]);
+          const float tk = sw ? k[j] : k[i];
+          const float uk = sw ? k[i] : k[j];
+          const uint32_t ti = sw ? id[j] : id[i];
+          const uint32_t ui = sw ? id[i] : id[j];
+          k[i] = tk; k[j] = uk; id[i] = ti; id[j] = ui;
+        }
+      }
+    }
+  }
+}
+
+// merge step of the same network: input bitonic, output descending
+template <int N>
+__device__ __forceinline__ void bitonic_merge_desc(float (&k)[N], uint32_t (&id)[N]) {
+#pragma unroll
+  for (int stride = N >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int j = i ^ stride;
+      if (j > i) {
+        const bool sw = better(k[j], id[j], k[i], id[i]);
+        const float tk = sw ? k[j] : k[i];
+        const float uk = sw ? k[i] : k[j];
+        const uint32_t ti = sw ? id[j] : id[i];
+        const uint32_t ui = sw ? id[i] : id[j];
+        k[i] = tk; k[j] = uk; id[i] = ti; id[j] = ui;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lane-private candidate list.
+//
+// In both scan kernels a lane owns ONE query (MFMA column = lane & 31) and sees half of every
+// 32-candidate tile (lane >> 5 picks the half), so candidates of a query are collected by exactly
+// two lanes, l and l ^ 32, each into its own list: no atomics, no cross-wave traffic.
+// Entry e of thread t lives at keys[e * NT + t] / ids[e * NT + t] (NT = threads per block):
+// consecutive lanes hit consecutive banks.
+//
+// Invariant: thr <= (kk-th best key of the query over everything scanned so far) - margin, so a
+// column whose key can still belong to the final top-kk always passes `key >= thr`.
+// ---------------------------------------------------------------------------------------------
+template <int CAP, int NT>
+struct LaneList {
+  static constexpr int SORTN = (CAP <= 16) ? 16 : 32;
+  float* keys;     // LDS, already offset by threadIdx.x
+  uint32_t* ids;   // LDS, already offset by threadIdx.x
+  int cnt;
+  float thr;
+  uint32_t overflow;
+
+  __device__ __forceinline__ void init(float* k, uint32_t* i) {
+    keys = k; ids = i; cnt = 0; thr = -kFltMax; overflow = 0;
+  }
+
+  __device__ __forceinline__ void push(float key, uint32_t id) {
+    keys[cnt * NT] = key;
+    ids[cnt * NT] = id;
+    ++cnt;
+  }
+
+  // Wave-wide (every lane of the wave calls it, EXEC full).  kk = entries a query must retain,
+  // margin = 0 with EXACT = true (keys are final: truncate to the top kk by the total order),
+  // margin = 2e > 0 otherwise (keys are approximate: keep everything within the margin).
+  template <bool EXACT>
+  __device__ __forceinline__ void compact(int kk, float margin) {
+    if constexpr (CAP <= 16) compact_sorted<EXACT>(kk, margin);
+    else compact_ranked<EXACT>(kk, margin);
+  }
+
+  __device__ __forceinline__ void raise_thr(float t, float margin, bool exact) {
+    // fewer than kk real entries in the union -> t = -inf -> keep collecting everything
+    const float nthr = (t == kNegInf) ? -kFltMax : (exact ? t : (t - margin));
+    if (nthr > thr) thr = nthr;
+  }
+
+  // CAP <= 16: both lists sorted in registers by a bitonic network, merged with the partner's.
+  template <bool EXACT>
+  __device__ __forceinline__ void compact_sorted(int kk, float margin) {
+    float k[SORTN];
+    uint32_t id[SORTN];
+#pragma unroll
+    for (int e = 0; e < SORTN; ++e) {
+      const bool live = (e < CAP) && (e < cnt);
+      k[e] = live ? keys[(e < CAP ? e : 0) * NT] : kNegInf;
+      id[e] = live ? ids[(e < CAP ? e : 0) * NT] : kNoIdx;
+    }
+    sort_desc<SORTN>(k, id);
+    // top SORTN of the union with the partner lane (same query, other half of every tile):
+    // c[i] = best(a[i], b[SORTN-1-i]) is the bitonic partition of two descending lists.
+    float c[SORTN];
+    uint32_t ci[SORTN];
+#pragma unroll
+    for (int e = 0; e < SORTN; ++e) {
+      const float pk = __shfl_xor(k[SORTN - 1 - e], 32);
+      const uint32_t pi = (uint32_t)__shfl_xor((int)id[SORTN - 1 - e], 32);
+      const bool own = better(k[e], id[e], pk, pi);
+      c[e] = own ? k[e] : pk;
+      ci[e] = own ? id[e] : pi;
+    }
+    bitonic_merge_desc<SORTN>(c, ci);
+    // kk-th best of the union (kk is wave-uniform): select chain, no dynamic register index
+    float t = kNegInf;
+#pragma unroll
+    for (int e = 0; e < SORTN; ++e) {
+      if (e == kk - 1) t = c[e];
+    }
+    raise_thr(t, margin, EXACT);
+    int keep = 0;
+#pragma unroll
+    for (int e = 0; e < CAP; ++e) {
+      const bool pass = (e < cnt) && (k[e] >= thr);
+      keep += pass ? 1 : 0;
+    }
+    if (EXACT) {
+      if (keep > kk) keep = kk;  // own top-kk by the total order is all the union can need
+    } else if (keep > CAP - 2) {
+      overflow = 1;              // too many columns inside the margin: the row is rescanned exactly
+      keep = CAP - 2;
+    }
+#pragma unroll
+    for (int e = 0; e < CAP; ++e) {
+      if (e < keep) { keys[e * NT] = k[e]; ids[e * NT] = id[e]; }
+    }
+    cnt = keep;
+  }
+
+  // CAP > 16 (large k, rare): ranks by counting straight out of LDS; the partner's list is read in
+  // place (same wave, so its LDS writes are already ordered before these reads).
+  template <bool EXACT>
+  __device__ __forceinline__ void compact_ranked(int kk, float margin) {
+    const int pofs = (int)((threadIdx.x ^ 32u) - threadIdx.x);
+    const int pcnt = __shfl_xor(cnt, 32);
+    uint32_t topmask = 0;
+    float t_own = kNegInf;
+    for (int e = 0; e < cnt; ++e) {
+      const float ke = keys[e * NT];
+      const uint32_t ie = ids[e * NT];
+      int r_own = 0, r_par = 0;
+      for (int f = 0; f < cnt; ++f) r_own += better(keys[f * NT], ids[f * NT], ke, ie) ? 1 : 0;
+      for (int f = 0; f < pcnt; ++f) r_par += better(keys[f * NT + pofs], ids[f * NT + pofs], ke, ie) ? 1 : 0;
+      if (r_own + r_par == kk - 1) t_own = ke;
+      if (r_own < kk) topmask |= 1u << e;
+    }
+    const float t = fmaxf(t_own, __shfl_xor(t_own, 32));
+    raise_thr(t, margin, EXACT);
+    int w = 0;
+    for (int e = 0; e < cnt; ++e) {
+      const float ke = keys[e * NT];
+      const uint32_t ie = ids[e * NT];
+      const bool kp = (ke >= thr) && (!EXACT || ((topmask >> e) & 1u));
+      if (kp) {
+        keys[w * NT] = ke;
+        ids[w * NT] = ie;
+        ++w;
+      }
+    }
+    if (!EXACT && w > CAP - 2) {
+      overflow = 1;
+      w = CAP - 2;
+    }
+    cnt = w;
+  }
+
+  // Offer the 16 keys one lane holds for one 32x32 accumulator tile.  v[r] belongs to candidate
+  // id0 + (r&3) + 8*(r>>2) + 4*(lane>>5).  Called by the whole wave when any lane has a hit.
+  template <bool EXACT>
+  __device__ __forceinline__ void offer_tile(const f32x16& v, uint32_t id0, int half, int kk, float margin) {
+#pragma unroll 1
+    for (int r = 0; r < 16; ++r) {
+      const float x = v[r];
+      bool hit = x >= thr;
+      if (__any(hit)) {
+        if (__any(hit && cnt >= CAP)) {
+          compact<EXACT>(kk, margin);
+          hit = x >= thr;
+        }
+        if (hit) {
+          if (cnt < CAP) push(x, id0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * half));
+          else overflow = 1;
+        }
+      }
+    }
+  }
+};
+
+__device__ __forceinline__ float max16(const f32x16& v) {
+  float a = fmaxf(fmaxf(v[0], v[1]), v[2]);
+  float b = fmaxf(fmaxf(v[3], v[4]), v[5]);
+  float c = fmaxf(fmaxf(v[6], v[7]), v[8]);
+  float d = fmaxf(fmaxf(v[9], v[10]), v[11]);
+  float e = fmaxf(fmaxf(v[12], v[13]), v[14]);
+  return fmaxf(fmaxf(fmaxf(a, b), fmaxf(c, d)), fmaxf(e, v[15]));
+}
+
+}  // namespace mmf

@@ -1,0 +1,165 @@
+// mmf_edges.hip — threshold edge builder over a dense [n,n] similarity (row a4 of SURVEY.md §8).
+//
+//  * lower median of the n(n-1) off-diagonal entries: 4-pass 8-bit radix select on the
+//    order-preserving integer image of the floats; HBM-bound (4 reads of K), no sort, no copy.
+//    Replaces: K[~eye] gather + torch.median, build_hypergraph/similarity_kernel.py:183-186.
+//  * row-major stream compaction of the entries that are NOT below the threshold (self loops
+//    kept): count per row -> exclusive scan -> ordered fill with wave ballots.
+//    Replaces: the Python double loop with .item(), build_hypergraph/similarity_kernel.py:193-202.
+#include "mmf_dev.h"
+#include "mmf_host.h"
+
+namespace mmf {
+
+__device__ __forceinline__ uint32_t f2ord(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+  const uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+
+// state (u64 units): hist[256], then prefix (low 32 bits), then rank
+struct MedianState {
+  unsigned long long hist[256];
+  unsigned long long prefix;
+  unsigned long long rank;
+};
+
+__global__ void median_init_kernel(MedianState* st, unsigned long long rank) {
+  if (threadIdx.x < 256) st->hist[threadIdx.x] = 0ull;
+  if (threadIdx.x == 0) { st->prefix = 0ull; st->rank = rank; }
+}
+
+__global__ __launch_bounds__(256) void median_hist_kernel(const float* __restrict__ K, int64_t n, MedianState* st,
+                                                          int shift) {
+  __shared__ unsigned int lh[256];
+  lh[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t prefix = (uint32_t)st->prefix;
+  const uint32_t himask = (shift == 24) ? 0u : (0xffffffffu << (shift + 8));
+  const int64_t total = n * n;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / n, j = e - i * n;
+    if (i == j) continue;
+    const uint32_t o = f2ord(K[e]);
+    if ((o & himask) == (prefix & himask)) atomicAdd(&lh[(o >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  if (lh[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+}
+
+__global__ void median_pick_kernel(MedianState* st, int shift, float* out) {
+  if (threadIdx.x == 0) {
+    unsigned long long r = st->rank;
+    int b = 0;
+    for (; b < 255; ++b) {
+      const unsigned long long c = st->hist[b];
+      if (r < c) break;
+      r -= c;
+    }
+    st->rank = r;
+    st->prefix = st->prefix | ((unsigned long long)b << shift);
+    if (shift == 0) *out = ord2f((uint32_t)st->prefix);
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) st->hist[threadIdx.x] = 0ull;
+}
+
+int launch_offdiag_lower_median(const float* K, int64_t n, float* out, uint32_t* scratch, hipStream_t s) {
+  MedianState* st = reinterpret_cast<MedianState*>(scratch);
+  const unsigned long long cnt = (unsigned long long)n * (unsigned long long)(n - 1);
+  hipLaunchKernelGGL(median_init_kernel, dim3(1), dim3(256), 0, s, st, (cnt - 1) / 2);
+  MMF_LAUNCH_CHECK();
+  const int64_t total = n * n;
+  int64_t grid = (total + 256 * 8 - 1) / (256 * 8);
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hipLaunchKernelGGL(median_hist_kernel, dim3((unsigned)grid), dim3(256), 0, s, K, n, st, shift);
+    MMF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(median_pick_kernel, dim3(1), dim3(256), 0, s, st, shift, out);
+    MMF_LAUNCH_CHECK();
+  }
+  return MMF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// threshold edges
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void thr_count_kernel(const float* __restrict__ K, int64_t n, float thr,
+                                                        uint32_t* __restrict__ row_cnt) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  uint32_t c = 0;
+  for (int64_t j = lane; j < n; j += 64) c += (K[row * n + j] < thr) ? 0u : 1u;  // skipped iff K < thr (:198)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor((int)c, o);
+  if (lane == 0) row_cnt[row] = c;
+}
+
+__global__ __launch_bounds__(1024) void thr_scan_kernel(const uint32_t* __restrict__ row_cnt, int64_t n,
+                                                        unsigned long long* __restrict__ row_off,
+                                                        int64_t* __restrict__ out_count) {
+  __shared__ unsigned long long part[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (n + 1023) / 1024;
+  const int64_t b = (int64_t)t * per;
+  int64_t e = b + per;
+  if (e > n) e = n;
+  unsigned long long sum = 0;
+  for (int64_t i = b; i < e; ++i) sum += row_cnt[i];
+  part[t] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    unsigned long long v = (t >= o) ? part[t - o] : 0ull;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  unsigned long long run = (t == 0) ? 0ull : part[t - 1];
+  for (int64_t i = b; i < e; ++i) { row_off[i] = run; run += row_cnt[i]; }
+  if (t == 1023) *out_count = (int64_t)part[1023];
+}
+
+__global__ __launch_bounds__(256) void thr_fill_kernel(const float* __restrict__ K, int64_t n, float thr,
+                                                       const unsigned long long* __restrict__ row_off,
+                                                       int64_t* __restrict__ ei, float* __restrict__ ew,
+                                                       int64_t capacity) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  unsigned long long pos = row_off[row];
+  for (int64_t j0 = 0; j0 < n; j0 += 64) {
+    const int64_t j = j0 + lane;
+    const float v = (j < n) ? K[row * n + j] : 0.0f;
+    const bool keep = (j < n) && !(v < thr);
+    const unsigned long long mask = __ballot(keep);
+    if (keep) {
+      const unsigned long long p = pos + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+      if ((int64_t)p < capacity) { ei[p] = row; ei[capacity + p] = j; ew[p] = v; }
+    }
+    pos += (unsigned long long)__popcll(mask);
+  }
+}
+
+int launch_threshold_edges(const float* K, int64_t n, float thr, int64_t* ei, float* ew, int64_t capacity,
+                           int64_t* out_count, uint32_t* scratch, size_t scratch_u32, hipStream_t s) {
+  if ((size_t)(2 * (n + 1) + n) > scratch_u32) { set_error("threshold_edges: scratch too small"); return MMF_E_INTERNAL; }
+  unsigned long long* row_off = reinterpret_cast<unsigned long long*>(scratch);
+  uint32_t* row_cnt = scratch + 2 * (n + 1);
+  const unsigned grid = (unsigned)((n + 3) / 4);
+  hipLaunchKernelGGL(thr_count_kernel, dim3(grid), dim3(256), 0, s, K, n, thr, row_cnt);
+  MMF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(thr_scan_kernel, dim3(1), dim3(1024), 0, s, row_cnt, n, row_off, out_count);
+  MMF_LAUNCH_CHECK();
+  if (capacity > 0) {
+    hipLaunchKernelGGL(thr_fill_kernel, dim3(grid), dim3(256), 0, s, K, n, thr, row_off, ei, ew, capacity);
+    MMF_LAUNCH_CHECK();
+  }
+  return MMF_OK;
+}
+
+}  // namespace mmf

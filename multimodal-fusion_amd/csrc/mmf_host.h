@@ -1,0 +1,142 @@
+// mmf_host.h — host-side plumbing of libmmf_hg.so: error reporting, per-(device,stream)
+// grow-only workspaces, launch checks, and the internal kernel-launcher prototypes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+
+#include "../../include/mmf_hg.h"
+
+namespace mmf {
+
+void set_error(const char* fmt, ...);
+
+#define MMF_HIP(call)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (call);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      mmf::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return MMF_E_HIP;                                                                    \
+    }                                                                                      \
+  } while (0)
+
+#define MMF_LAUNCH_CHECK()                                                                 \
+  do {                                                                                     \
+    hipError_t _e = hipGetLastError();                                                     \
+    if (_e != hipSuccess) {                                                                \
+      mmf::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+      return MMF_E_HIP;                                                                    \
+    }                                                                                      \
+  } while (0)
+
+#define MMF_TRY(expr)            \
+  do {                           \
+    int _rc = (expr);            \
+    if (_rc != MMF_OK) return _rc; \
+  } while (0)
+
+// Bump allocator over one cached device buffer per (device, stream).
+struct Workspace {
+  char* base = nullptr;
+  size_t cap = 0;
+  size_t off = 0;
+  void reset() { off = 0; }
+  template <typename T>
+  T* take(size_t count) {
+    size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
+    T* p = reinterpret_cast<T*>(base + off);
+    off += bytes;
+    return p;
+  }
+};
+inline size_t ws_bytes(size_t count, size_t elem) { return (count * elem + 255) & ~size_t(255); }
+
+// Returns a workspace of at least `bytes` for (device, stream); reallocates (after a stream sync)
+// when it has to grow.
+int get_workspace(int device, hipStream_t stream, size_t bytes, Workspace* out);
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+inline size_t dtype_size(int dt) { return dt == MMF_F32 ? 4 : 2; }
+
+// ------------------------------------------------------------------------------------------------
+// kernel launchers (one translation unit each)
+// ------------------------------------------------------------------------------------------------
+
+// mmf_prep.hip: canonical squared norms (or clamped norms for cosine) of every row.
+int launch_row_scalars(const void* X, int64_t n, int64_t d, int dtype, int metric, float* out,
+                       hipStream_t s);
+
+// candidate lists written by the scan kernels and read by the select kernel:
+//   cnt[(row * lists + l)]            number of ids in list l of the row
+//   ids[(row * lists + l) * cap + e]  LOCAL column index (0..m-1)
+struct CandLists {
+  uint32_t* cnt;
+  uint32_t* ids;
+  uint32_t* overflow;  // [n] nonzero when a list of the row overflowed
+  int lists;           // lists per row = 2 * col_splits
+  int cap;
+};
+
+struct ScanProblem {
+  const void* X; int64_t n;       // query rows
+  const void* Y; int64_t m;       // candidate rows (columns of the similarity matrix)
+  int64_t d;
+  int dtype;
+  int metric;
+  float lambda;
+  int kk;                         // entries to retain per query (k, +1 when self is excluded later)
+  const float* rx;                // per-row scalar of X  (launch_row_scalars)
+  const float* cy;                // per-row scalar of Y
+  const int32_t* row_ids;         // optional: scan only these rows of X (fallback), else nullptr
+  int64_t n_rows;                 // number of rows to scan (== n when row_ids == nullptr)
+  int col_splits;
+};
+
+// mmf_scan_f32.hip: exact scan on v_mfma_f32_32x32x2_f32 (any d, f32/bf16/f16 inputs).
+int scan_f32_cap(int kk);  // list capacity the kernel will use for kk (0 = unsupported)
+int launch_scan_f32(const ScanProblem& p, const CandLists& L, hipStream_t s, int* grid_out);
+
+// mmf_select.hip: canonical keys of the candidates, self dropped, top-k by (key desc, id asc).
+struct SelectProblem {
+  const void* X; int64_t n; const void* Y; int64_t m; int64_t d; int dtype; int metric; float lambda;
+  int k; int exclude_self; int64_t row_offset; int64_t col_offset;
+  const float* rx; const float* cy;
+  const int32_t* row_ids; int64_t n_rows;
+  int64_t* out_idx; float* out_val;
+  int32_t* fail_rows; uint32_t* fail_count;   // rows whose lists overflowed (or came up short)
+  uint32_t* cand_total;                        // optional accumulated candidate count
+};
+int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s);
+int launch_topk_merge(const int64_t* ia, const float* va, const int64_t* ib, const float* vb,
+                      int64_t n, int k, int64_t* io, float* vo, hipStream_t s);
+int launch_edge_cosine(const void* X, int64_t n, int64_t d, int dtype, const int64_t* ei, int64_t E,
+                       float* out, hipStream_t s);
+
+// mmf_dense.hip
+int launch_sim_dense(const void* X, int64_t n, const void* Y, int64_t m, int64_t d, int dtype,
+                     int metric, float lambda, const float* rx, const float* cy, float* out,
+                     hipStream_t s);
+int launch_sim_dense_combined(const float* F, const float* P, int64_t n, int64_t d, int64_t dp,
+                              float lambda_h, float lambda_g, const float* nf, float* out,
+                              hipStream_t s);
+
+// mmf_edges.hip
+int launch_offdiag_lower_median(const float* K, int64_t n, float* out, uint32_t* scratch /*>=1024 u32*/,
+                                hipStream_t s);
+int launch_threshold_edges(const float* K, int64_t n, float thr, int64_t* ei, float* ew,
+                           int64_t capacity, int64_t* out_count, uint32_t* scratch, size_t scratch_u32,
+                           hipStream_t s);
+
+}  // namespace mmf

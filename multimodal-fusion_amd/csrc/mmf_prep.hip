@@ -1,0 +1,53 @@
+// mmf_prep.hip — per-row scalars in canonical arithmetic.
+//
+// n_i = chain(x_i, x_i) is a k-ordered fmaf chain (include/mmf_hg.h), so one lane owns one row and
+// walks k in order; tiles of 64 rows x 64 k are staged through LDS so the global reads stay
+// coalesced (64 consecutive elements of one row per wave instruction).
+// Replaces: torch.sum(features ** 2, dim=1, keepdim=True), build_hypergraph/similarity_kernel.py:43,79.
+#include "mmf_dev.h"
+#include "mmf_host.h"
+
+namespace mmf {
+
+constexpr int PREP_WAVES = 4;
+
+__global__ __launch_bounds__(64 * PREP_WAVES) void row_scalars_kernel(const void* __restrict__ X, int64_t n,
+                                                                        int64_t d, int dtype, int metric,
+                                                                        float* __restrict__ out) {
+  __shared__ float tile[PREP_WAVES][64][65];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t row0 = ((int64_t)blockIdx.x * PREP_WAVES + wave) * 64;
+  float acc = 0.0f;
+  for (int64_t k0 = 0; k0 < d; k0 += 64) {
+    const int64_t k = k0 + lane;
+#pragma unroll 8
+    for (int r = 0; r < 64; ++r) {
+      const int64_t row = row0 + r;
+      float v = 0.0f;
+      if (row < n && k < d) v = ld_elem(X, row * d + k, dtype);
+      tile[wave][r][lane] = v;
+    }
+    __syncthreads();
+    const int kend = (d - k0 < 64) ? (int)(d - k0) : 64;
+    for (int kk = 0; kk < kend; ++kk) {
+      const float v = tile[wave][lane][kk];
+      acc = __builtin_fmaf(v, v, acc);
+    }
+    __syncthreads();
+  }
+  const int64_t row = row0 + lane;
+  if (row < n) out[row] = (metric == MMF_COSINE) ? clamped_norm(acc) : acc;
+}
+
+int launch_row_scalars(const void* X, int64_t n, int64_t d, int dtype, int metric, float* out, hipStream_t s) {
+  if (n <= 0) return MMF_OK;
+  const int64_t rows_per_block = 64 * PREP_WAVES;
+  const int64_t grid = (n + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL(row_scalars_kernel, dim3((unsigned)grid), dim3(64 * PREP_WAVES), 0, s, X, n, d, dtype,
+                     metric, out);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+
+}  // namespace mmf

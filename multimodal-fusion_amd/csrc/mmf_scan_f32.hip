@@ -1,0 +1,386 @@
+// mmf_scan_f32.hip — exact all-pairs scan on v_mfma_f32_32x32x2_f32, any d, f32/bf16/f16 inputs.
+//
+// One kernel template, two epilogues:
+//   MODE_SCAN  : fused similarity + per-row top-k candidates (the N x M matrix never leaves the CU)
+//   MODE_DENSE : writes the [n,m] similarity for the small-N reference signatures
+//
+// The f32-input MFMA accumulates D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)), i.e. exactly the k-ordered
+// fmaf chain of include/mmf_hg.h (cdna_hip_programming.md §3 "FP32-input MFMA"), so the keys formed
+// here ARE the canonical keys: lists are truncated by the final total order and cannot overflow.
+//
+// Tiling: workgroup = 4 waves = 128 queries x 128 candidates per macro tile, K staged through LDS in
+// chunks of 32 (double buffered, one barrier per chunk).  Wave w owns queries 32w..32w+31 as the MFMA
+// column (B operand) and sweeps the 4 candidate sub-tiles as MFMA rows (A operand), so every lane
+// keeps ONE query and its candidate list is lane-private (mmf_dev.h).
+// LDS rows are padded to 33 floats: lanes 0..31 of a ds_read_b32 hit 32 distinct banks.
+//
+// Replaces: torch.mm + 3 elementwise passes, build_hypergraph/similarity_kernel.py:43-52, 79-84, 122;
+//           sklearn brute-force kneighbors, build_hypergraph/preprocess_hypergraph.py:379-382.
+#include "mmf_dev.h"
+#include "mmf_host.h"
+
+namespace mmf {
+
+constexpr int F_NT = 256;
+constexpr int F_QT = 128;
+constexpr int F_CT = 128;
+constexpr int F_KC = 32;
+constexpr int F_LD = 33;
+
+constexpr int MODE_SCAN = 0;
+constexpr int MODE_DENSE = 1;
+
+struct ScanF32Args {
+  const void* X; const void* Y;
+  int64_t n, m, d;
+  int dtype;
+  const float* rx; const float* cy;
+  const int32_t* row_ids; int64_t n_rows;
+  float neg_lambda;
+  int metric;
+  int kk;
+  int col_splits;
+  int64_t tiles_per_split;
+  uint32_t* cand_cnt; uint32_t* cand_ids; uint32_t* overflow;
+  // dense epilogue
+  float* out;
+  const float* P; int dp; float neg_lambda_g;
+};
+
+template <bool VEC4>
+__device__ __forceinline__ f32x4 load4(const void* base, int64_t row, int64_t k, int64_t d, int dtype) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (VEC4) {
+    if (k < d) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + row * d + k);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (k + i < d) v[i] = ld_elem(base, row * d + k + i, dtype);
+  }
+  return v;
+}
+
+template <int MODE, int CAP, bool VEC4>
+__global__ __launch_bounds__(F_NT) void scan_f32_kernel(ScanF32Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Qs = reinterpret_cast<float*>(smem);   // [2][F_QT][F_LD]
+  float* Cs = Qs + 2 * F_QT * F_LD;             // [2][F_CT][F_LD]
+  float* lkeys = Cs + 2 * F_CT * F_LD;          // [CAP][F_NT]
+  uint32_t* lids = reinterpret_cast<uint32_t*>(lkeys + CAP * F_NT);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int half = lane >> 5;
+  const int c = lane & 31;
+
+  const int split = blockIdx.x % a.col_splits;
+  const int64_t rb = blockIdx.x / a.col_splits;
+  const int64_t q0 = rb * F_QT;
+
+  const int64_t total_tiles = (a.m + F_CT - 1) / F_CT;
+  int64_t t_begin = (int64_t)split * a.tiles_per_split;
+  int64_t t_end = t_begin + a.tiles_per_split;
+  if (t_end > total_tiles) t_end = total_tiles;
+  if (t_begin > t_end) t_begin = t_end;
+  const int nkc = (int)((a.d + F_KC - 1) / F_KC);
+  const int64_t steps = (t_end - t_begin) * nkc;
+
+  // this lane's query
+  const int64_t qpos = q0 + 32 * wave + c;
+  const bool qvalid = qpos < a.n_rows;
+  const int64_t qrow = qvalid ? (a.row_ids ? (int64_t)a.row_ids[qpos] : qpos) : 0;
+  const float ri = qvalid ? a.rx[qrow] : 1.0f;
+  const int metric = a.metric;
+
+  LaneList<CAP, F_NT> list;
+  if constexpr (MODE == MODE_SCAN) {
+    list.init(lkeys + tid, lids + tid);
+    if (!qvalid) list.thr = __builtin_huge_valf();
+  }
+
+  // staging roles: rows (tid>>3) + 32*i, k offset 4*(tid&7)
+  const int srow = tid >> 3;
+  const int sk = 4 * (tid & 7);
+  int64_t qsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int64_t p = q0 + srow + 32 * i;
+    if (p > a.n_rows - 1) p = a.n_rows - 1;
+    qsrc[i] = a.row_ids ? (int64_t)a.row_ids[p] : p;
+  }
+
+  f32x4 rq[4], rc[4];
+  auto gload = [&](int64_t step) {
+    const int64_t ct = t_begin + step / nkc;
+    const int64_t k = (int64_t)(step % nkc) * F_KC + sk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rq[i] = load4<VEC4>(a.X, qsrc[i], k, a.d, a.dtype);
+      int64_t j = ct * F_CT + srow + 32 * i;
+      if (j > a.m - 1) j = a.m - 1;
+      rc[i] = load4<VEC4>(a.Y, j, k, a.d, a.dtype);
+    }
+  };
+  auto swrite = [&](int buf) {
+    float* qd = Qs + buf * F_QT * F_LD + srow * F_LD + sk;
+    float* cd = Cs + buf * F_CT * F_LD + srow * F_LD + sk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        qd[i * 32 * F_LD + e] = rq[i][e];
+        cd[i * 32 * F_LD + e] = rc[i][e];
+      }
+    }
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  if (steps > 0) {
+    gload(0);
+    swrite(0);
+  }
+  __syncthreads();
+
+  for (int64_t s = 0; s < steps; ++s) {
+    const int buf = (int)(s & 1);
+    if (s + 1 < steps) gload(s + 1);
+
+    const float* Qb = Qs + buf * F_QT * F_LD + (32 * wave + c) * F_LD + half;
+    const float* Cb = Cs + buf * F_CT * F_LD + c * F_LD + half;
+#pragma unroll
+    for (int k2 = 0; k2 < F_KC / 2; ++k2) {
+      const float b = Qb[2 * k2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float av = Cb[t * 32 * F_LD + 2 * k2];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[t], 0, 0, 0);
+      }
+    }
+
+    if ((int)(s % nkc) == nkc - 1) {
+      const int64_t ct = t_begin + s / nkc;
+      f32x16 key[4];
+      float mx = kNegInf;
+      // keys in three wave-uniform flavours (no per-element switch): dot | dot/(r*c) | nl*((r+c)-2dot)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int64_t cand0 = ct * F_CT + 32 * t;
+        float cj[16];
+        bool jv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t j = cand0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          jv[r] = j < a.m;
+          cj[r] = a.cy[jv[r] ? j : 0];
+        }
+        if (metric == MMF_DOT) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) key[t][r] = acc[t][r];
+        } else if (metric == MMF_COSINE) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) key[t][r] = key_from_dot<MMF_COSINE>(acc[t][r], ri, cj[r], 0.0f);
+        } else {
+          const float nl = (metric == MMF_RBF) ? a.neg_lambda : -1.0f;  // (-1)*sq == -sq exactly
+#pragma unroll
+          for (int r = 0; r < 16; ++r) key[t][r] = key_from_dot<MMF_RBF>(acc[t][r], ri, cj[r], nl);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          key[t][r] = jv[r] ? key[t][r] : kNegInf;
+          acc[t][r] = 0.0f;
+        }
+        if constexpr (MODE == MODE_SCAN) mx = fmaxf(mx, max16(key[t]));
+      }
+      if constexpr (MODE == MODE_SCAN) {
+        if (__any(mx >= list.thr)) {
+          // one call site for the slow path: walk the four sub-tiles with a uniform runtime index
+#pragma unroll 1
+          for (int t = 0; t < 4; ++t) {
+            const f32x16 v = (t == 0) ? key[0] : (t == 1) ? key[1] : (t == 2) ? key[2] : key[3];
+            if (__any(max16(v) >= list.thr))
+              list.template offer_tile<true>(v, (uint32_t)(ct * F_CT + 32 * t), half, a.kk, 0.0f);
+          }
+        }
+      } else {
+        if (qvalid) {
+          float* orow = a.out + qrow * a.m;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int64_t j = ct * F_CT + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+              if (j < a.m) {
+                float v = (metric == MMF_RBF) ? expf(key[t][r]) : key[t][r];
+                if (a.P) {
+                  // K_g from the positions, canonical chains over dp (similarity_kernel.py:79-84, 122)
+                  float ni = 0.f, nj = 0.f, dp_ = 0.f;
+                  for (int e = 0; e < a.dp; ++e) {
+                    const float pi = a.P[qrow * a.dp + e], pj = a.P[j * a.dp + e];
+                    ni = __builtin_fmaf(pi, pi, ni);
+                    nj = __builtin_fmaf(pj, pj, nj);
+                    dp_ = __builtin_fmaf(pi, pj, dp_);
+                  }
+                  const float kg = expf(a.neg_lambda_g * sq_from(ni, nj, dp_));
+                  v = v * kg;
+                }
+                orow[j] = v;
+              }
+            }
+          }
+        }
+      }
+    }
+
+    if (s + 1 < steps) swrite(buf ^ 1);
+    __syncthreads();
+  }
+
+  if constexpr (MODE == MODE_SCAN) {
+    list.template compact<true>(a.kk, 0.0f);
+    if (qvalid) {
+      const int64_t lbase = qpos * (2 * a.col_splits) + 2 * split + half;
+      a.cand_cnt[lbase] = (uint32_t)list.cnt;
+      for (int e = 0; e < list.cnt; ++e) a.cand_ids[lbase * CAP + e] = list.ids[e * F_NT];
+      if (list.overflow) atomicOr(a.overflow + qpos, 1u);
+    }
+  }
+}
+
+// direct-difference RBF, preprocess_hypergraph.py:254-256: out = exp(-lambda * sum_k (a_k - b_k)^2)
+__global__ __launch_bounds__(256) void rbf_direct_kernel(const void* __restrict__ X, int64_t n,
+                                                         const void* __restrict__ Y, int64_t m, int64_t d,
+                                                         int dtype, float neg_lambda, float* __restrict__ out) {
+  __shared__ float Xs[32][33];
+  __shared__ float Ys[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int64_t i0 = (int64_t)blockIdx.y * 32, j0 = (int64_t)blockIdx.x * 32;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t k0 = 0; k0 < d; k0 += 32) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = ty + 8 * r;
+      const int64_t k = k0 + tx;
+      Xs[rr][tx] = (i0 + rr < n && k < d) ? ld_elem(X, (i0 + rr) * d + k, dtype) : 0.0f;
+      Ys[rr][tx] = (j0 + rr < m && k < d) ? ld_elem(Y, (j0 + rr) * d + k, dtype) : 0.0f;
+    }
+    __syncthreads();
+    const int kend = (d - k0 < 32) ? (int)(d - k0) : 32;
+    for (int kk = 0; kk < kend; ++kk) {
+      const float yv = Ys[tx][kk];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t = Xs[ty + 8 * r][kk] - yv;
+        acc[r] = __builtin_fmaf(t, t, acc[r]);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = i0 + ty + 8 * r, j = j0 + tx;
+    if (i < n && j < m) out[i * m + j] = expf(neg_lambda * acc[r]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+int scan_f32_cap(int kk) {
+  if (kk <= 12) return 16;
+  if (kk <= 28) return 32;
+  return 0;
+}
+
+static size_t scan_f32_lds(int cap) {
+  return sizeof(float) * (2 * F_QT * F_LD + 2 * F_CT * F_LD) + (size_t)cap * F_NT * 8;
+}
+
+template <int MODE, int CAP>
+static int launch_f32_t(const ScanF32Args& a, bool vec4, int64_t grid, hipStream_t s) {
+  if (a.metric < MMF_DOT || a.metric > MMF_RBF) {
+    set_error("scan_f32: unsupported metric %d", a.metric);
+    return MMF_E_INVALID;
+  }
+  const size_t lds = scan_f32_lds(MODE == MODE_SCAN ? CAP : 0);
+  auto go = [&](auto kern) -> int {
+    MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(F_NT), lds, s, a);
+    MMF_LAUNCH_CHECK();
+    return MMF_OK;
+  };
+  if (vec4) return go(scan_f32_kernel<MODE, CAP, true>);
+  return go(scan_f32_kernel<MODE, CAP, false>);
+}
+
+static bool can_vec4(const void* X, const void* Y, int64_t d, int dtype) {
+  return dtype == MMF_F32 && (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
+         ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
+}
+
+int launch_scan_f32(const ScanProblem& p, const CandLists& L, hipStream_t s, int* grid_out) {
+  if (p.n_rows <= 0 || p.m <= 0) return MMF_OK;
+  ScanF32Args a{};
+  a.X = p.X; a.Y = p.Y; a.n = p.n; a.m = p.m; a.d = p.d; a.dtype = p.dtype;
+  a.rx = p.rx; a.cy = p.cy; a.row_ids = p.row_ids; a.n_rows = p.n_rows;
+  a.neg_lambda = -p.lambda; a.kk = p.kk; a.col_splits = p.col_splits;
+  const int64_t total_tiles = (p.m + F_CT - 1) / F_CT;
+  a.tiles_per_split = (total_tiles + p.col_splits - 1) / p.col_splits;
+  a.cand_cnt = L.cnt; a.cand_ids = L.ids; a.overflow = L.overflow;
+  const int64_t grid = ((p.n_rows + F_QT - 1) / F_QT) * p.col_splits;
+  if (grid_out) *grid_out = (int)grid;
+  const bool v4 = can_vec4(p.X, p.Y, p.d, p.dtype);
+  a.metric = p.metric;
+  if (L.cap == 16) return launch_f32_t<MODE_SCAN, 16>(a, v4, grid, s);
+  if (L.cap == 32) return launch_f32_t<MODE_SCAN, 32>(a, v4, grid, s);
+  set_error("scan_f32: unsupported list capacity %d", L.cap);
+  return MMF_E_INTERNAL;
+}
+
+int launch_sim_dense(const void* X, int64_t n, const void* Y, int64_t m, int64_t d, int dtype, int metric,
+                     float lambda, const float* rx, const float* cy, float* out, hipStream_t s) {
+  if (n <= 0 || m <= 0) return MMF_OK;
+  if (metric == MMF_RBF_DIRECT) {
+    dim3 grid((unsigned)((m + 31) / 32), (unsigned)((n + 31) / 32));
+    hipLaunchKernelGGL(rbf_direct_kernel, grid, dim3(256), 0, s, X, n, Y, m, d, dtype, -lambda, out);
+    MMF_LAUNCH_CHECK();
+    return MMF_OK;
+  }
+  ScanF32Args a{};
+  a.X = X; a.Y = Y; a.n = n; a.m = m; a.d = d; a.dtype = dtype;
+  a.rx = rx; a.cy = cy; a.row_ids = nullptr; a.n_rows = n;
+  a.neg_lambda = -lambda; a.kk = 0;
+  const int64_t total_tiles = (m + F_CT - 1) / F_CT;
+  const int64_t rbs = (n + F_QT - 1) / F_QT;
+  int64_t splits = (1024 + rbs - 1) / rbs;
+  if (splits > total_tiles) splits = total_tiles;
+  if (splits < 1) splits = 1;
+  a.col_splits = (int)splits;
+  a.tiles_per_split = (total_tiles + splits - 1) / splits;
+  a.out = out;
+  a.metric = metric;
+  return launch_f32_t<MODE_DENSE, 16>(a, can_vec4(X, Y, d, dtype), rbs * splits, s);
+}
+
+int launch_sim_dense_combined(const float* F, const float* P, int64_t n, int64_t d, int64_t dp, float lambda_h,
+                              float lambda_g, const float* nf, float* out, hipStream_t s) {
+  if (n <= 0) return MMF_OK;
+  ScanF32Args a{};
+  a.X = F; a.Y = F; a.n = n; a.m = n; a.d = d; a.dtype = MMF_F32;
+  a.rx = nf; a.cy = nf; a.row_ids = nullptr; a.n_rows = n;
+  a.neg_lambda = -lambda_h; a.kk = 0;
+  const int64_t total_tiles = (n + F_CT - 1) / F_CT;
+  const int64_t rbs = (n + F_QT - 1) / F_QT;
+  int64_t splits = (1024 + rbs - 1) / rbs;
+  if (splits > total_tiles) splits = total_tiles;
+  a.col_splits = (int)splits;
+  a.tiles_per_split = (total_tiles + splits - 1) / splits;
+  a.out = out; a.P = P; a.dp = (int)dp; a.neg_lambda_g = -lambda_g;
+  a.metric = MMF_RBF;
+  return launch_f32_t<MODE_DENSE, 16>(a, can_vec4(F, F, d, MMF_F32), rbs * splits, s);
+}
+
+}  // namespace mmf

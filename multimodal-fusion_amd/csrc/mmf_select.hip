@@ -1,0 +1,242 @@
+// mmf_select.hip — exact re-rank of the scan's candidates and the final per-row top-k; plus the
+// two small list kernels of the ABI (topk merge, per-edge cosine weights).
+//
+// select: one wave per query row.  Every candidate's key is recomputed as the canonical k-ordered
+// fmaf chain from the ORIGINAL inputs (one lane per candidate walks k in order), self is dropped by
+// identity, and k rounds of a wave-wide arg-best under (key desc, id asc) emit the row.  The result
+// therefore does not depend on which scan kernel produced the candidates, on tile shapes, column
+// splits or shard counts.
+// Replaces: "indices[i, 1:]" (drop column 0) of preprocess_hypergraph.py:386-388 and the score
+//           passes of similarity_kernel.py:49-52 for the pairs that survive.
+#include "mmf_dev.h"
+#include "mmf_host.h"
+
+namespace mmf {
+
+constexpr int SEL_WAVES = 4;
+constexpr int SEL_MAXC = 1024;  // candidates per row the kernel can hold (lists * cap must fit)
+
+struct SelectArgs {
+  const void* X; const void* Y; int64_t n, m, d; int dtype;
+  float neg_lambda; int k; int exclude_self; int64_t row_offset, col_offset;
+  const float* rx; const float* cy;
+  const int32_t* row_ids; int64_t n_rows;
+  const uint32_t* cand_cnt; const uint32_t* cand_ids; const uint32_t* overflow; int lists; int cap;
+  int64_t* out_idx; float* out_val;
+  int32_t* fail_rows; uint32_t* fail_count; uint32_t* cand_total;
+};
+
+template <bool VEC4>
+__device__ __forceinline__ float chain_rows(const void* X, int64_t xr, const void* Y, int64_t yr, int64_t d,
+                                            int dtype) {
+  float acc = 0.0f;
+  if constexpr (VEC4) {
+    const f32x4* xp = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(X) + xr * d);
+    const f32x4* yp = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(Y) + yr * d);
+    const int64_t d4 = d >> 2;
+    for (int64_t q = 0; q < d4; ++q) {
+      const f32x4 xv = xp[q], yv = yp[q];
+      acc = __builtin_fmaf(xv[0], yv[0], acc);
+      acc = __builtin_fmaf(xv[1], yv[1], acc);
+      acc = __builtin_fmaf(xv[2], yv[2], acc);
+      acc = __builtin_fmaf(xv[3], yv[3], acc);
+    }
+  } else {
+    for (int64_t k = 0; k < d; ++k)
+      acc = __builtin_fmaf(ld_elem(X, xr * d + k, dtype), ld_elem(Y, yr * d + k, dtype), acc);
+  }
+  return acc;
+}
+
+template <int METRIC, bool VEC4>
+__global__ __launch_bounds__(64 * SEL_WAVES) void select_kernel(SelectArgs a) {
+  __shared__ float skey[SEL_WAVES][SEL_MAXC];
+  __shared__ uint32_t sid[SEL_WAVES][SEL_MAXC];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t pos = (int64_t)blockIdx.x * SEL_WAVES + wave;
+  if (pos >= a.n_rows) return;
+  const int64_t row = a.row_ids ? (int64_t)a.row_ids[pos] : pos;
+  float* key = skey[wave];
+  uint32_t* id = sid[wave];
+
+  bool failed = a.overflow[pos] != 0;
+  int total = 0;
+  if (!failed) {
+    for (int l = 0; l < a.lists; ++l) {
+      const uint32_t cn = a.cand_cnt[pos * a.lists + l];
+      if (total + (int)cn > SEL_MAXC) { failed = true; break; }
+      for (uint32_t e = lane; e < cn; e += 64) id[total + e] = a.cand_ids[(pos * a.lists + l) * a.cap + e];
+      total += (int)cn;
+    }
+  }
+  const int64_t grow = a.row_offset + row;
+  int valid = 0;
+  if (!failed) {
+    __builtin_amdgcn_wave_barrier();
+    const float ri = a.rx[row];
+    for (int e = lane; e < total; e += 64) {
+      const uint32_t j = id[e];
+      const bool self = a.exclude_self && (a.col_offset + (int64_t)j == grow);
+      float kx = kNegInf;
+      if (!self && (int64_t)j < a.m) {
+        const float dot = chain_rows<VEC4>(a.X, row, a.Y, (int64_t)j, a.d, a.dtype);
+        kx = key_from_dot<METRIC>(dot, ri, a.cy[j], a.neg_lambda);
+        if (kx != kx) kx = kNegInf;  // NaN keys rank last (documented: undefined for non-finite inputs)
+        ++valid;
+      } else {
+        id[e] = kNoIdx;
+      }
+      key[e] = kx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) valid += __shfl_xor(valid, o);
+    if (valid < a.k) failed = true;
+  }
+  if (failed) {
+    if (lane == 0) {
+      const uint32_t slot = atomicAdd(a.fail_count, 1u);
+      a.fail_rows[slot] = (int32_t)pos;
+    }
+    return;
+  }
+  if (a.cand_total && lane == 0) atomicAdd(a.cand_total + (blockIdx.x & 255), (uint32_t)total);
+  __builtin_amdgcn_wave_barrier();
+  for (int t = 0; t < a.k; ++t) {
+    float bk = kNegInf;
+    uint32_t bi = kNoIdx;
+    int be = -1;
+    for (int e = lane; e < total; e += 64) {
+      const uint32_t ie = id[e];
+      if (ie != kNoIdx && (be < 0 || better(key[e], ie, bk, bi))) { bk = key[e]; bi = ie; be = e; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ok = __shfl_xor(bk, o);
+      const uint32_t oi = (uint32_t)__shfl_xor((int)bi, o);
+      const int oe = __shfl_xor(be, o);
+      const bool take = (oe >= 0) && (be < 0 || better(ok, oi, bk, bi));
+      if (take) { bk = ok; bi = oi; be = oe; }
+    }
+    // every lane now agrees on (bk, bi, be); the owner retires the entry
+    if (be >= 0 && (be & 63) == lane) id[be] = kNoIdx;
+    if (lane == 0) {
+      a.out_idx[row * a.k + t] = a.col_offset + (int64_t)bi;
+      a.out_val[row * a.k + t] = val_from_key<METRIC>(bk);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int METRIC>
+static int launch_select_m(const SelectArgs& a, bool vec4, hipStream_t s) {
+  const int64_t grid = (a.n_rows + SEL_WAVES - 1) / SEL_WAVES;
+  if (vec4) hipLaunchKernelGGL((select_kernel<METRIC, true>), dim3((unsigned)grid), dim3(64 * SEL_WAVES), 0, s, a);
+  else hipLaunchKernelGGL((select_kernel<METRIC, false>), dim3((unsigned)grid), dim3(64 * SEL_WAVES), 0, s, a);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+
+int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
+  if (p.n_rows <= 0) return MMF_OK;
+  if ((int64_t)L.lists * L.cap > SEL_MAXC) {
+    set_error("select: %d lists x %d entries exceed the per-row capacity %d", L.lists, L.cap, SEL_MAXC);
+    return MMF_E_INTERNAL;
+  }
+  SelectArgs a{};
+  a.X = p.X; a.Y = p.Y; a.n = p.n; a.m = p.m; a.d = p.d; a.dtype = p.dtype;
+  a.neg_lambda = -p.lambda; a.k = p.k; a.exclude_self = p.exclude_self;
+  a.row_offset = p.row_offset; a.col_offset = p.col_offset; a.rx = p.rx; a.cy = p.cy;
+  a.row_ids = p.row_ids; a.n_rows = p.n_rows;
+  a.cand_cnt = L.cnt; a.cand_ids = L.ids; a.overflow = L.overflow; a.lists = L.lists; a.cap = L.cap;
+  a.out_idx = p.out_idx; a.out_val = p.out_val;
+  a.fail_rows = p.fail_rows; a.fail_count = p.fail_count; a.cand_total = p.cand_total;
+  const bool v4 = p.dtype == MMF_F32 && (p.d % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0) &&
+                  ((reinterpret_cast<uintptr_t>(p.Y) & 15) == 0);
+  switch (p.metric) {
+    case MMF_DOT: return launch_select_m<MMF_DOT>(a, v4, s);
+    case MMF_COSINE: return launch_select_m<MMF_COSINE>(a, v4, s);
+    case MMF_NEG_SQ_L2: return launch_select_m<MMF_NEG_SQ_L2>(a, v4, s);
+    case MMF_RBF: return launch_select_m<MMF_RBF>(a, v4, s);
+  }
+  set_error("select: unsupported metric %d", p.metric);
+  return MMF_E_INVALID;
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge two sorted [n,k] lists; one lane per row
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool better64(float ka, int64_t ia, float kb, int64_t ib) {
+  if (ka != ka) ka = kNegInf;
+  if (kb != kb) kb = kNegInf;
+  return (ka > kb) || (ka == kb && ia < ib);
+}
+
+__global__ void topk_merge_kernel(const int64_t* __restrict__ ia, const float* __restrict__ va,
+                                  const int64_t* __restrict__ ib, const float* __restrict__ vb, int64_t n, int k,
+                                  int64_t* __restrict__ io, float* __restrict__ vo) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int64_t *pa = ia + r * k, *pb = ib + r * k;
+  const float *qa = va + r * k, *qb = vb + r * k;
+  int a = 0, b = 0, o = 0;
+  while (o < k) {
+    while (a < k && pa[a] < 0) ++a;
+    while (b < k && pb[b] < 0) ++b;
+    const bool ta = a < k, tb = b < k;
+    if (!ta && !tb) break;
+    bool pick_a;
+    if (ta && tb) {
+      if (pa[a] == pb[b]) { ++b; continue; }
+      pick_a = better64(qa[a], pa[a], qb[b], pb[b]);
+    } else {
+      pick_a = ta;
+    }
+    const int64_t id = pick_a ? pa[a] : pb[b];
+    const float v = pick_a ? qa[a] : qb[b];
+    if (pick_a) ++a; else ++b;
+    bool dup = false;
+    for (int t = 0; t < o; ++t) dup |= (io[r * k + t] == id);
+    if (dup) continue;
+    io[r * k + o] = id;
+    vo[r * k + o] = v;
+    ++o;
+  }
+  for (; o < k; ++o) { io[r * k + o] = -1; vo[r * k + o] = kNegInf; }
+}
+
+int launch_topk_merge(const int64_t* ia, const float* va, const int64_t* ib, const float* vb, int64_t n, int k,
+                      int64_t* io, float* vo, hipStream_t s) {
+  if (n <= 0) return MMF_OK;
+  hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ia, va, ib, vb, n, k,
+                     io, vo);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// w_e = max(0, cos(x_i, x_j)), preprocess_hypergraph.py:414-420.  nrm = clamped norms of the rows.
+// ------------------------------------------------------------------------------------------------
+template <bool VEC4>
+__global__ void edge_cosine_kernel(const void* __restrict__ X, int64_t d, int dtype, const float* __restrict__ nrm,
+                                   const int64_t* __restrict__ ei, int64_t E, float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int64_t i = ei[e], j = ei[E + e];
+  const float dot = chain_rows<VEC4>(X, i, X, j, d, dtype);
+  const float c = dot / (nrm[i] * nrm[j]);
+  out[e] = (c > 0.0f) ? c : 0.0f;
+}
+
+int launch_edge_cosine_impl(const void* X, int64_t d, int dtype, const float* nrm, const int64_t* ei, int64_t E,
+                            float* out, hipStream_t s) {
+  if (E <= 0) return MMF_OK;
+  const bool v4 = dtype == MMF_F32 && (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  const dim3 grid((unsigned)((E + 127) / 128));
+  if (v4) hipLaunchKernelGGL(edge_cosine_kernel<true>, grid, dim3(128), 0, s, X, d, dtype, nrm, ei, E, out);
+  else hipLaunchKernelGGL(edge_cosine_kernel<false>, grid, dim3(128), 0, s, X, d, dtype, nrm, ei, E, out);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+
+}  // namespace mmf

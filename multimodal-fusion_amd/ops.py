@@ -1,0 +1,166 @@
+"""Torch-tensor front end of the C ABI: device pointers, current stream, output allocation.
+
+Every function requires tensors on a ROCm device (``tensor.is_cuda``); nothing here computes on
+the host.  The reference-signature mirrors in ``build_hypergraph`` sit on top of this module.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
+
+
+def _need_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor is on {t.device}; this op runs only on a ROCm device "
+                           "(the package has no CPU path)")
+
+
+def _feat(t: torch.Tensor, what: str) -> torch.Tensor:
+    if t.dim() != 2:
+        raise ValueError(f"{what}: expected a 2-D [N, D] tensor, got shape {tuple(t.shape)}")
+    if t.dtype not in _DT:
+        t = t.float()
+    return t.contiguous()
+
+
+def _stream(dev: torch.device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _metric(m) -> int:
+    if isinstance(m, str):
+        if m not in _lib.METRICS:
+            raise ValueError(f"unknown metric {m!r}")
+        return _lib.METRICS[m]
+    return int(m)
+
+
+def simtopk(X: torch.Tensor, Y: Optional[torch.Tensor] = None, *, metric="cosine", lam: float = 1.0, k: int = 5,
+            exclude_self: Optional[bool] = None, row_offset: int = 0, col_offset: int = 0, precision: str = "auto",
+            profile: bool = False, col_splits: int = 0, return_stats: bool = False):
+    """Fused similarity + per-row top-k (mmf_simtopk_ex).  Returns (idx int64 [n,k], val f32 [n,k])."""
+    X = _feat(X, "simtopk X")
+    _need_gpu(X, "simtopk")
+    if Y is not None:
+        Y = _feat(Y, "simtopk Y")
+        if Y.device != X.device or Y.dtype != X.dtype or Y.shape[1] != X.shape[1]:
+            raise ValueError("simtopk: X and Y must share device, dtype and feature dim")
+    if exclude_self is None:
+        exclude_self = Y is None
+    n, d = X.shape
+    m = n if Y is None else Y.shape[0]
+    idx = torch.empty((n, k), dtype=torch.int64, device=X.device)
+    val = torch.empty((n, k), dtype=torch.float32, device=X.device)
+    opts = _lib.SimtopkOpts(_lib.PRECISIONS[precision], int(profile), int(col_splits), 0)
+    stats = _lib.SimtopkStats()
+    rc = _lib.lib().mmf_simtopk_ex(_p(X), n, _p(Y), m, d, _DT[X.dtype], _metric(metric), float(lam), int(k),
+                                   int(bool(exclude_self)), int(row_offset), int(col_offset), _p(idx), _p(val),
+                                   ctypes.byref(opts), ctypes.byref(stats), X.device.index or 0, _stream(X.device))
+    _lib.check(rc, "mmf_simtopk")
+    if return_stats:
+        return idx, val, stats.as_dict()
+    return idx, val
+
+
+def sim_dense(X: torch.Tensor, Y: Optional[torch.Tensor] = None, *, metric="rbf", lam: float = 1.0) -> torch.Tensor:
+    X = _feat(X, "sim_dense X")
+    _need_gpu(X, "sim_dense")
+    if Y is not None:
+        Y = _feat(Y, "sim_dense Y").to(X.dtype)
+        if Y.device != X.device or Y.shape[1] != X.shape[1]:
+            raise ValueError("sim_dense: X and Y must share device and feature dim")
+    n, d = X.shape
+    m = n if Y is None else Y.shape[0]
+    out = torch.empty((n, m), dtype=torch.float32, device=X.device)
+    rc = _lib.lib().mmf_sim_dense(_p(X), n, _p(Y), m, d, _DT[X.dtype], _metric(metric), float(lam), _p(out),
+                                  X.device.index or 0, _stream(X.device))
+    _lib.check(rc, "mmf_sim_dense")
+    return out
+
+
+def sim_dense_combined(F: torch.Tensor, P: torch.Tensor, lambda_h: float = 1.0, lambda_g: float = 1.0) -> torch.Tensor:
+    F = _feat(F, "sim_dense_combined features").float()
+    P = _feat(P, "sim_dense_combined positions").float()
+    _need_gpu(F, "sim_dense_combined")
+    if P.device != F.device or P.shape[0] != F.shape[0]:
+        raise ValueError("sim_dense_combined: features and positions must share device and N")
+    n, d = F.shape
+    out = torch.empty((n, n), dtype=torch.float32, device=F.device)
+    rc = _lib.lib().mmf_sim_dense_combined(_p(F), _p(P), n, d, P.shape[1], float(lambda_h), float(lambda_g), _p(out),
+                                           F.device.index or 0, _stream(F.device))
+    _lib.check(rc, "mmf_sim_dense_combined")
+    return out
+
+
+def edge_cosine(X: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
+    X = _feat(X, "edge_cosine X")
+    _need_gpu(X, "edge_cosine")
+    ei = edge_index.to(device=X.device, dtype=torch.int64).contiguous()
+    if ei.dim() != 2 or ei.shape[0] != 2:
+        raise ValueError("edge_cosine: edge_index must be [2, E]")
+    E = ei.shape[1]
+    if E and (int(ei.min()) < 0 or int(ei.max()) >= X.shape[0]):
+        raise ValueError("edge_cosine: edge_index out of range")
+    out = torch.empty((E,), dtype=torch.float32, device=X.device)
+    rc = _lib.lib().mmf_edge_cosine(_p(X), X.shape[0], X.shape[1], _DT[X.dtype], _p(ei), E, _p(out),
+                                    X.device.index or 0, _stream(X.device))
+    _lib.check(rc, "mmf_edge_cosine")
+    return out
+
+
+def topk_merge(ia: torch.Tensor, va: torch.Tensor, ib: torch.Tensor, vb: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    _need_gpu(ia, "topk_merge")
+    ia, ib = ia.contiguous().long(), ib.contiguous().long()
+    va, vb = va.contiguous().float(), vb.contiguous().float()
+    if ia.shape != ib.shape or ia.shape != va.shape or ia.shape != vb.shape or ia.dim() != 2:
+        raise ValueError("topk_merge: all four inputs must be [n, k]")
+    n, k = ia.shape
+    io = torch.empty_like(ia)
+    vo = torch.empty_like(va)
+    rc = _lib.lib().mmf_topk_merge(_p(ia), _p(va), _p(ib), _p(vb), n, k, _p(io), _p(vo), ia.device.index or 0,
+                                   _stream(ia.device))
+    _lib.check(rc, "mmf_topk_merge")
+    return io, vo
+
+
+def offdiag_lower_median(K: torch.Tensor) -> torch.Tensor:
+    """Lower median of the off-diagonal entries of a square f32 matrix; returns a 0-d device tensor."""
+    _need_gpu(K, "offdiag_lower_median")
+    K = K.contiguous().float()
+    if K.dim() != 2 or K.shape[0] != K.shape[1]:
+        raise ValueError("offdiag_lower_median: K must be square")
+    out = torch.empty((), dtype=torch.float32, device=K.device)
+    rc = _lib.lib().mmf_offdiag_lower_median(_p(K), K.shape[0], _p(out), K.device.index or 0, _stream(K.device))
+    _lib.check(rc, "mmf_offdiag_lower_median")
+    return out
+
+
+def threshold_edges(K: torch.Tensor, threshold: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Row-major (i, j) with K[i, j] not below `threshold` -> (edge_index [2,E] int64, weights [E] f32)."""
+    _need_gpu(K, "threshold_edges")
+    K = K.contiguous().float()
+    if K.dim() != 2 or K.shape[0] != K.shape[1]:
+        raise ValueError("threshold_edges: K must be square")
+    n = K.shape[0]
+    cnt = torch.zeros((), dtype=torch.int64, device=K.device)
+    L = _lib.lib()
+    dev, st = K.device.index or 0, _stream(K.device)
+    # pass 1: count only (capacity 0); pass 2: fill exactly
+    _lib.check(L.mmf_threshold_edges(_p(K), n, float(threshold), None, None, 0, _p(cnt), dev, st), "mmf_threshold_edges")
+    E = int(cnt.item())
+    ei = torch.empty((2, E), dtype=torch.int64, device=K.device)
+    ew = torch.empty((E,), dtype=torch.float32, device=K.device)
+    if E:
+        _lib.check(L.mmf_threshold_edges(_p(K), n, float(threshold), _p(ei), _p(ew), E, _p(cnt), dev, st),
+                   "mmf_threshold_edges")
+    return ei, ew
