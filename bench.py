@@ -25,7 +25,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {1: 157.3, 2: 2500.0}   # MMF_PREC_EXACT: f32 MFMA; MMF_PREC_FAST: bf16 MFMA dense (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {1: 157.3, 2: 2500.0, 3: 2500.0}   # f32 MFMA; f16 / bf16 MFMA dense (MI355X_MICROARCH.md)
+SCAN_NAME = {1: "scan_f32 (v_mfma_f32_32x32x2_f32)", 2: "scan_b16<f16> (v_mfma_f32_32x32x16_f16)", 3: "scan_b16<bf16> (v_mfma_f32_32x32x16_bf16)"}
 
 
 def make_rows(lo: int, hi: int, d: int, device, block: int = 4096):
@@ -74,7 +75,7 @@ def main() -> None:
     ap.add_argument("--d", type=int, default=512)
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--metric", default="cosine")
-    ap.add_argument("--precision", default="auto", choices=["auto", "exact", "fast"])
+    ap.add_argument("--precision", default="auto", choices=["auto", "exact", "fast", "fast_bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -139,16 +140,16 @@ def main() -> None:
             "metric": "similarity-pairs/sec (NxN cosine+top-k)", "value": pairs / (elapsed / args.steps),
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "bf16 MFMA scan + f32 exact re-rank" if prec == 2 else "f32",
+            "dtype": {1: "f32", 2: "f16 MFMA scan + f32 exact re-rank", 3: "bf16 MFMA scan + f32 exact re-rank"}[prec],
             "data": "synthetic",
             "config": {"workload": f"N={n} d={d} single-modality {args.metric} + top-{k}, self excluded, f32 features",
                        "rows_per_rank": hi - lo, "parallelism": f"row-shard x{world}, one all-gather of the feature shard",
-                       "scan_kernel": "bf16" if prec == 2 else "f32", "col_splits": stats["col_splits"],
+                       "scan_kernel": SCAN_NAME[prec], "col_splits": stats["col_splits"],
                        "scan_grid": stats["scan_grid"], "fallback_rows": stats["fallback_rows"],
                        "candidates_per_row": stats["candidates"] / max(1, hi - lo)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": None,
-                         "kernel": "scan_bf16" if prec == 2 else "scan_f32", "kernel_ms": scan_avg_ms,
+                         "kernel": SCAN_NAME[prec], "kernel_ms": scan_avg_ms,
                          "prep_ms": stats["prep_ms"], "rerank_ms": stats["rerank_ms"], "fallback_ms": stats["fallback_ms"]},
         }
         if world == 1 and not args.no_cpu_baseline:

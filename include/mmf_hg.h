@@ -68,7 +68,9 @@ extern "C" {
  * the N x M pairs. */
 #define MMF_PREC_AUTO  0  /* FAST when the shape is supported by the bf16 kernel, else EXACT */
 #define MMF_PREC_EXACT 1  /* v_mfma_f32_32x32x2_f32 scan, canonical keys in-kernel           */
-#define MMF_PREC_FAST  2  /* bf16/f16 MFMA scan with a proven error margin + exact f32 re-rank */
+#define MMF_PREC_FAST  2  /* f16 MFMA scan (rows scaled by an exact power of two) with a proven error
+                             margin + exact f32 re-rank; overflowed rows are rescanned exactly      */
+#define MMF_PREC_FAST_BF16 3 /* same with bf16 operands: 8x larger rounding residual, wider margin    */
 
 int         mmf_version(void);
 const char* mmf_last_error(void);
@@ -112,6 +114,8 @@ typedef struct mmf_simtopk_stats {
   int      col_splits;     /* column ranges per row block actually used                         */
   int      scan_grid;      /* workgroups launched by the scan kernel                             */
   int      reserved0;
+  int64_t  overflow_rows;  /* fallback rows whose candidate list overflowed (near-ties beyond capacity) */
+  int64_t  short_rows;     /* fallback rows whose lists held fewer than k admissible candidates   */
 } mmf_simtopk_stats;
 
 int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d,

@@ -12,7 +12,7 @@ MMF_OK, MMF_E_INVALID, MMF_E_UNSUPPORTED, MMF_E_HIP, MMF_E_NOMEM, MMF_E_INTERNAL
 DOT, COSINE, NEG_SQ_L2, RBF, RBF_DIRECT = 0, 1, 2, 3, 4
 METRICS = {"dot": DOT, "cosine": COSINE, "neg_sq_l2": NEG_SQ_L2, "rbf": RBF, "rbf_direct": RBF_DIRECT}
 F32, BF16, F16 = 0, 1, 2
-PRECISIONS = {"auto": 0, "exact": 1, "fast": 2}
+PRECISIONS = {"auto": 0, "exact": 1, "fast": 2, "fast_bf16": 3}
 
 
 class SimtopkOpts(ctypes.Structure):
@@ -24,7 +24,7 @@ class SimtopkStats(ctypes.Structure):
     _fields_ = [("scan_ms", ctypes.c_float), ("prep_ms", ctypes.c_float), ("rerank_ms", ctypes.c_float),
                 ("fallback_ms", ctypes.c_float), ("candidates", ctypes.c_int64), ("fallback_rows", ctypes.c_int64),
                 ("precision_used", ctypes.c_int), ("col_splits", ctypes.c_int), ("scan_grid", ctypes.c_int),
-                ("reserved0", ctypes.c_int)]
+                ("reserved0", ctypes.c_int), ("overflow_rows", ctypes.c_int64), ("short_rows", ctypes.c_int64)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_ if not f.startswith("reserved")}

@@ -54,8 +54,18 @@ int get_workspace(int device, hipStream_t stream, size_t bytes, Workspace* out) 
 int launch_edge_cosine_impl(const void* X, int64_t d, int dtype, const float* nrm, const int64_t* ei, int64_t E,
                             float* out, hipStream_t s);
 
-// mmf_scan_bf16.hip (fast path); returns 0 capacity when the shape is not supported
+// mmf_scan_bf16.hip (fast path)
 int scan_bf16_supported(int64_t d, int kk, int dtype);
+int scan_bf16_cap();
+int scan_bf16_dp(int64_t d);
+int launch_prep_half(const void* X, int64_t n, int64_t d, int dtype, int metric, const float* scal,
+                     const uint32_t* max_n, void* Z,
+                     int64_t n_pad, int dp, int z_f16, float* zn, float* rn, float* un, float* cb, uint32_t* maxima,
+                     hipStream_t s);
+int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float* q_zn, const float* q_rn,
+                    const float* q_un, const uint32_t* maxima, int64_t n_rows, int64_t m, int64_t m_pad, int dp,
+                    int64_t d, bool f16, int metric, int kk, int col_splits, const CandLists& L, hipStream_t s,
+                    int* grid_out);
 
 static int check_common(const void* X, int64_t n, int64_t m, int64_t d, int in_dtype, int device_id) {
   if (device_id < 0) {
@@ -164,16 +174,142 @@ int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d
   const bool profile = opts && opts->profile;
   const int forced_splits = opts ? opts->col_splits : 0;
   if (precision == MMF_PREC_AUTO) precision = scan_bf16_supported(d, kk, in_dtype) ? MMF_PREC_FAST : MMF_PREC_EXACT;
-  if (precision == MMF_PREC_FAST && !scan_bf16_supported(d, kk, in_dtype)) {
+  if (precision != MMF_PREC_EXACT && precision != MMF_PREC_FAST && precision != MMF_PREC_FAST_BF16) {
+    set_error("simtopk: bad precision %d", precision);
+    return MMF_E_INVALID;
+  }
+  if (precision != MMF_PREC_EXACT && !scan_bf16_supported(d, kk, in_dtype)) {
     set_error("simtopk: MMF_PREC_FAST does not support d = %lld, k = %d (use AUTO or EXACT)", (long long)d, k);
     return MMF_E_UNSUPPORTED;
   }
   const int cap = scan_f32_cap(kk);
   if (cap == 0) { set_error("simtopk: k = %d is above the supported maximum (27 with self excluded, 28 without)", k); return MMF_E_UNSUPPORTED; }
 
-  if (precision == MMF_PREC_FAST) {
-    set_error("simtopk: fast path not built");
-    return MMF_E_UNSUPPORTED;
+  if (precision != MMF_PREC_EXACT) {
+    // ---- fast path: bf16/f16 MFMA scan -> exact re-rank -> exact rescan of overflowed rows -------
+    const int dp = scan_bf16_dp(d);
+    const bool f16 = (precision == MMF_PREC_FAST);   // operand type of the scan, not of the input
+    const int bcap = scan_bf16_cap();
+    const bool same = (Y == X) && (m == n);
+    const int64_t n_pad = (n + 255) / 256 * 256, m_pad = (m + 255) / 256 * 256;
+    const int64_t row_blocks = n_pad / 256, col_tiles = m_pad / 32;
+    int splits = 1;
+    if (forced_splits > 0) { while (splits < forced_splits) splits <<= 1; }
+    else { while (row_blocks * splits < 256 && splits < 32) splits <<= 1; }
+    while (splits > 1 && (splits > col_tiles || 2 * splits * bcap > 1024)) splits >>= 1;
+    const int lists = 2 * splits;
+    // exact rescans are done in batches of at most FB rows
+    const int64_t FB = n < 4096 ? n : 4096;
+    const int64_t fb_blocks = (FB + 127) / 128, fb_tiles = (m + 127) / 128;
+    const int fb_splits = pick_splits(fb_blocks, fb_tiles, 0, cap, 0);
+    const int fb_lists = 2 * fb_splits;
+    size_t need = ws_bytes(n, 4) + ws_bytes(m, 4) + ws_bytes((size_t)n_pad * dp, 2) + ws_bytes((size_t)m_pad * dp, 2) +
+                  4 * ws_bytes(n_pad, 4) + 4 * ws_bytes(m_pad, 4) + 3 * ws_bytes(4, 4) +
+                  ws_bytes((size_t)n * lists, 4) + ws_bytes((size_t)n * lists * bcap, 4) + 2 * ws_bytes(n, 4) +
+                  ws_bytes(4, 4) + ws_bytes(256, 4) + ws_bytes((size_t)FB * fb_lists, 4) +
+                  ws_bytes((size_t)FB * fb_lists * cap, 4) + 2 * ws_bytes(FB, 4) + ws_bytes(4, 4);
+    Workspace ws;
+    MMF_TRY(get_workspace(device_id, s, need, &ws));
+    float* rx = ws.take<float>(n);
+    float* cy = same ? rx : ws.take<float>(m);
+    uint16_t* ZQ = ws.take<uint16_t>((size_t)n_pad * dp);
+    uint16_t* ZC = same ? ZQ : ws.take<uint16_t>((size_t)m_pad * dp);
+    float* q_zn = ws.take<float>(n_pad); float* q_rn = ws.take<float>(n_pad);
+    float* q_un = ws.take<float>(n_pad); float* q_cb = ws.take<float>(n_pad);
+    float *c_zn = q_zn, *c_rn = q_rn, *c_un = q_un, *c_cb = q_cb;
+    if (!same) { c_zn = ws.take<float>(m_pad); c_rn = ws.take<float>(m_pad); c_un = ws.take<float>(m_pad); c_cb = ws.take<float>(m_pad); }
+    uint32_t* max_q = ws.take<uint32_t>(4);
+    uint32_t* max_c = same ? max_q : ws.take<uint32_t>(4);
+    uint32_t* max_n = ws.take<uint32_t>(4);   // largest squared row norm over X and Y -> common scale
+    CandLists L;
+    L.cnt = ws.take<uint32_t>((size_t)n * lists);
+    L.ids = ws.take<uint32_t>((size_t)n * lists * bcap);
+    L.overflow = ws.take<uint32_t>(n);
+    L.lists = lists; L.cap = bcap;
+    int32_t* fail_rows = ws.take<int32_t>(n);
+    uint32_t* fail_count = ws.take<uint32_t>(4);
+    uint32_t* cand_total = ws.take<uint32_t>(256);
+    CandLists FL;
+    FL.cnt = ws.take<uint32_t>((size_t)FB * fb_lists);
+    FL.ids = ws.take<uint32_t>((size_t)FB * fb_lists * cap);
+    FL.overflow = ws.take<uint32_t>(FB);
+    FL.lists = fb_lists; FL.cap = cap;
+    int32_t* fb_fail_rows = ws.take<int32_t>(FB);
+    uint32_t* fb_fail_count = ws.take<uint32_t>(4);
+
+    MMF_HIP(hipMemsetAsync(L.overflow, 0, (size_t)n * 4, s));
+    MMF_HIP(hipMemsetAsync(fail_count, 0, 16, s));
+    MMF_HIP(hipMemsetAsync(cand_total, 0, 1024, s));
+    MMF_HIP(hipMemsetAsync(max_q, 0, 16, s));
+    MMF_HIP(hipMemsetAsync(max_n, 0, 16, s));
+    if (!same) MMF_HIP(hipMemsetAsync(max_c, 0, 16, s));
+
+    EventTimer t_prep, t_scan, t_sel, t_fb;
+    MMF_TRY(t_prep.start(profile, s));
+    MMF_TRY(launch_row_scalars(X, n, d, in_dtype, metric, rx, max_n, s));
+    if (!same) MMF_TRY(launch_row_scalars(Y, m, d, in_dtype, metric, cy, max_n, s));
+    MMF_TRY(launch_prep_half(X, n, d, in_dtype, metric, rx, max_n, ZQ, n_pad, dp, f16 ? 1 : 0, q_zn, q_rn, q_un, q_cb, max_q, s));
+    if (!same) MMF_TRY(launch_prep_half(Y, m, d, in_dtype, metric, cy, max_n, ZC, m_pad, dp, f16 ? 1 : 0, c_zn, c_rn, c_un, c_cb, max_c, s));
+    MMF_TRY(t_prep.stop(s));
+
+    int grid = 0;
+    MMF_TRY(t_scan.start(profile, s));
+    MMF_TRY(launch_scan_b16(ZQ, ZC, c_cb, q_zn, q_rn, q_un, max_c, n, m, m_pad, dp, d, f16, metric, kk, splits, L, s, &grid));
+    MMF_TRY(t_scan.stop(s));
+
+    SelectProblem q{};
+    q.X = X; q.n = n; q.Y = Y; q.m = m; q.d = d; q.dtype = in_dtype; q.metric = metric; q.lambda = lambda;
+    q.k = k; q.exclude_self = exclude_self; q.row_offset = row_offset; q.col_offset = col_offset;
+    q.rx = rx; q.cy = cy; q.row_ids = nullptr; q.n_rows = n; q.out_idx = out_idx; q.out_val = out_val;
+    q.fail_rows = fail_rows; q.fail_count = fail_count; q.cand_total = stats ? cand_total : nullptr;
+    MMF_TRY(t_sel.start(profile, s));
+    MMF_TRY(launch_select(q, L, s));
+    MMF_TRY(t_sel.stop(s));
+
+    uint32_t h_fail4[4] = {0, 0, 0, 0};
+    MMF_HIP(hipMemcpyAsync(h_fail4, fail_count, 16, hipMemcpyDeviceToHost, s));
+    std::vector<uint32_t> h_tot(stats ? 256 : 0);
+    if (stats) MMF_HIP(hipMemcpyAsync(h_tot.data(), cand_total, 1024, hipMemcpyDeviceToHost, s));
+    MMF_HIP(hipStreamSynchronize(s));
+    const uint32_t h_fail = h_fail4[0];
+    if (stats) { stats->overflow_rows = h_fail4[1]; stats->short_rows = h_fail4[2]; }
+
+    MMF_TRY(t_fb.start(profile && h_fail > 0, s));
+    for (int64_t off = 0; off < (int64_t)h_fail; off += FB) {
+      const int64_t nb = ((int64_t)h_fail - off < FB) ? ((int64_t)h_fail - off) : FB;
+      MMF_HIP(hipMemsetAsync(FL.overflow, 0, (size_t)nb * 4, s));
+      MMF_HIP(hipMemsetAsync(fb_fail_count, 0, 16, s));
+      ScanProblem sp{};
+      sp.X = X; sp.n = n; sp.Y = Y; sp.m = m; sp.d = d; sp.dtype = in_dtype; sp.metric = metric; sp.lambda = lambda;
+      sp.kk = kk; sp.rx = rx; sp.cy = cy; sp.row_ids = fail_rows + off; sp.n_rows = nb; sp.col_splits = fb_splits;
+      MMF_TRY(launch_scan_f32(sp, FL, s, nullptr));
+      SelectProblem fq = q;
+      fq.row_ids = fail_rows + off; fq.n_rows = nb; fq.fail_rows = fb_fail_rows; fq.fail_count = fb_fail_count;
+      fq.cand_total = nullptr;
+      MMF_TRY(launch_select(fq, FL, s));
+      uint32_t h_fb = 0;
+      MMF_HIP(hipMemcpyAsync(&h_fb, fb_fail_count, 4, hipMemcpyDeviceToHost, s));
+      MMF_HIP(hipStreamSynchronize(s));
+      if (h_fb != 0) {
+        set_error("simtopk: %u rows failed in the exact rescan (internal invariant)", h_fb);
+        return MMF_E_INTERNAL;
+      }
+    }
+    MMF_TRY(t_fb.stop(s));
+    if (stats) {
+      stats->precision_used = precision;
+      stats->col_splits = splits;
+      stats->scan_grid = grid;
+      stats->prep_ms = t_prep.ms();
+      stats->scan_ms = t_scan.ms();
+      stats->rerank_ms = t_sel.ms();
+      stats->fallback_ms = t_fb.ms();
+      stats->fallback_rows = h_fail;
+      int64_t tot = 0;
+      for (uint32_t v : h_tot) tot += v;
+      stats->candidates = tot;
+    }
+    return MMF_OK;
   }
 
   // ---- exact path ------------------------------------------------------------------------------
@@ -202,8 +338,8 @@ int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d
 
   EventTimer t_prep, t_scan, t_sel;
   MMF_TRY(t_prep.start(profile, s));
-  MMF_TRY(launch_row_scalars(X, n, d, in_dtype, metric, rx, s));
-  if (!same) MMF_TRY(launch_row_scalars(Y, m, d, in_dtype, metric, cy, s));
+  MMF_TRY(launch_row_scalars(X, n, d, in_dtype, metric, rx, nullptr, s));
+  if (!same) MMF_TRY(launch_row_scalars(Y, m, d, in_dtype, metric, cy, nullptr, s));
   MMF_TRY(t_prep.stop(s));
 
   ScanProblem sp{};
@@ -276,7 +412,7 @@ int mmf_edge_cosine(const void* X, int64_t n, int64_t d, int in_dtype, const int
   Workspace ws;
   MMF_TRY(get_workspace(device_id, s, ws_bytes(n, 4), &ws));
   float* nrm = ws.take<float>(n);
-  MMF_TRY(launch_row_scalars(X, n, d, in_dtype, MMF_COSINE, nrm, s));
+  MMF_TRY(launch_row_scalars(X, n, d, in_dtype, MMF_COSINE, nrm, nullptr, s));
   return launch_edge_cosine_impl(X, d, in_dtype, nrm, edge_index, E, out_w, s);
 }
 
@@ -297,8 +433,8 @@ int mmf_sim_dense(const void* X, int64_t n, const void* Y, int64_t m, int64_t d,
     MMF_TRY(get_workspace(device_id, s, ws_bytes(n, 4) + ws_bytes(m, 4), &ws));
     rx = ws.take<float>(n);
     cy = same ? rx : ws.take<float>(m);
-    MMF_TRY(launch_row_scalars(X, n, d, in_dtype, metric, rx, s));
-    if (!same) MMF_TRY(launch_row_scalars(Y, m, d, in_dtype, metric, cy, s));
+    MMF_TRY(launch_row_scalars(X, n, d, in_dtype, metric, rx, nullptr, s));
+    if (!same) MMF_TRY(launch_row_scalars(Y, m, d, in_dtype, metric, cy, nullptr, s));
   }
   return launch_sim_dense(X, n, Y, m, d, in_dtype, metric, lambda, rx, cy, out, s);
 }
@@ -315,7 +451,7 @@ int mmf_sim_dense_combined(const float* F, const float* P, int64_t n, int64_t d,
   Workspace ws;
   MMF_TRY(get_workspace(device_id, s, ws_bytes(n, 4), &ws));
   float* nf = ws.take<float>(n);
-  MMF_TRY(launch_row_scalars(F, n, d, MMF_F32, MMF_RBF, nf, s));
+  MMF_TRY(launch_row_scalars(F, n, d, MMF_F32, MMF_RBF, nf, nullptr, s));
   return launch_sim_dense_combined(F, P, n, d, dp, lambda_h, lambda_g, nf, out, s);
 }
 

@@ -135,10 +135,21 @@ struct LaneList {
   uint32_t* ids;   // LDS, already offset by threadIdx.x
   int cnt;
   float thr;
+  float lost;      // best approximate key ever dropped by a lossy truncation (-inf: nothing lost)
   uint32_t overflow;
 
   __device__ __forceinline__ void init(float* k, uint32_t* i) {
-    keys = k; ids = i; cnt = 0; thr = -kFltMax; overflow = 0;
+    keys = k; ids = i; cnt = 0; thr = -kFltMax; lost = kNegInf; overflow = 0;
+  }
+
+  // Approximate mode only.  A list can be crowded TRANSIENTLY: early in a scan the threshold is low
+  // and a cluster of near-identical columns puts more than CAP entries inside the margin band of
+  // the current k-th best, although the final top-k ends far above them.  So crowding truncates
+  // (lossy) instead of failing: the best dropped key is remembered in `lost`, the threshold is
+  // raised to it (nothing at or below a lost level is worth collecting), and the row fails only
+  // if, at the END, the final band still reaches down to a lost level: finish() checks that.
+  __device__ __forceinline__ void finish() {
+    if (lost >= thr) overflow = 1;
   }
 
   __device__ __forceinline__ void push(float key, uint32_t id) {
@@ -166,51 +177,84 @@ struct LaneList {
   template <bool EXACT>
   __device__ __forceinline__ void compact_sorted(int kk, float margin) {
     float k[SORTN];
-    uint32_t id[SORTN];
+    {
+      uint32_t id[SORTN];
 #pragma unroll
-    for (int e = 0; e < SORTN; ++e) {
-      const bool live = (e < CAP) && (e < cnt);
-      k[e] = live ? keys[(e < CAP ? e : 0) * NT] : kNegInf;
-      id[e] = live ? ids[(e < CAP ? e : 0) * NT] : kNoIdx;
+      for (int e = 0; e < SORTN; ++e) {
+        const bool live = (e < CAP) && (e < cnt);
+        k[e] = live ? keys[(e < CAP ? e : 0) * NT] : kNegInf;
+        id[e] = live ? ids[(e < CAP ? e : 0) * NT] : kNoIdx;
+      }
+      sort_desc<SORTN>(k, id);
+      if constexpr (!EXACT) {
+        // approximate keys: only the KEY order matters from here on; park the sorted list in LDS
+        // now so the ids leave the registers before the merge (register pressure: 128 VGPRs of
+        // resident query fragments live across this code in the bf16 kernel)
+#pragma unroll
+        for (int e = 0; e < CAP; ++e) { keys[e * NT] = k[e]; ids[e * NT] = id[e]; }
+      } else {
+        // final keys: the merge must break key ties by id, keep the pairs
+        float c[SORTN];
+        uint32_t ci[SORTN];
+#pragma unroll
+        for (int e = 0; e < SORTN; ++e) {
+          const float pk = __shfl_xor(k[SORTN - 1 - e], 32);
+          const uint32_t pi = (uint32_t)__shfl_xor((int)id[SORTN - 1 - e], 32);
+          const bool own = better(k[e], id[e], pk, pi);
+          c[e] = own ? k[e] : pk;
+          ci[e] = own ? id[e] : pi;
+        }
+        bitonic_merge_desc<SORTN>(c, ci);
+        float t = kNegInf;
+#pragma unroll
+        for (int e = 0; e < SORTN; ++e) {
+          if (e == kk - 1) t = c[e];
+        }
+        raise_thr(t, 0.0f, true);
+        int keep = 0;
+#pragma unroll
+        for (int e = 0; e < CAP; ++e) keep += ((e < cnt) && (k[e] >= thr)) ? 1 : 0;
+        if (keep > kk) keep = kk;  // own top-kk by the total order is all the union can need
+#pragma unroll
+        for (int e = 0; e < CAP; ++e) {
+          if (e < keep) { keys[e * NT] = k[e]; ids[e * NT] = id[e]; }
+        }
+        cnt = keep;
+        return;
+      }
     }
-    sort_desc<SORTN>(k, id);
-    // top SORTN of the union with the partner lane (same query, other half of every tile):
-    // c[i] = best(a[i], b[SORTN-1-i]) is the bitonic partition of two descending lists.
+    // !EXACT: top SORTN keys of the union with the partner lane (same query, other half of every
+    // tile): c[i] = max(a[i], b[SORTN-1-i]) is the bitonic partition of two descending lists, and
+    // the merge network on bare keys is pure v_max/v_min.
     float c[SORTN];
-    uint32_t ci[SORTN];
 #pragma unroll
-    for (int e = 0; e < SORTN; ++e) {
-      const float pk = __shfl_xor(k[SORTN - 1 - e], 32);
-      const uint32_t pi = (uint32_t)__shfl_xor((int)id[SORTN - 1 - e], 32);
-      const bool own = better(k[e], id[e], pk, pi);
-      c[e] = own ? k[e] : pk;
-      ci[e] = own ? id[e] : pi;
+    for (int e = 0; e < SORTN; ++e) c[e] = fmaxf(k[e], __shfl_xor(k[SORTN - 1 - e], 32));
+#pragma unroll
+    for (int stride = SORTN >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+      for (int i = 0; i < SORTN; ++i) {
+        const int j = i ^ stride;
+        if (j > i) {
+          const float hi = fmaxf(c[i], c[j]), lo = fminf(c[i], c[j]);
+          c[i] = hi; c[j] = lo;
+        }
+      }
     }
-    bitonic_merge_desc<SORTN>(c, ci);
-    // kk-th best of the union (kk is wave-uniform): select chain, no dynamic register index
     float t = kNegInf;
 #pragma unroll
     for (int e = 0; e < SORTN; ++e) {
       if (e == kk - 1) t = c[e];
     }
-    raise_thr(t, margin, EXACT);
+    raise_thr(t, margin, false);
     int keep = 0;
 #pragma unroll
-    for (int e = 0; e < CAP; ++e) {
-      const bool pass = (e < cnt) && (k[e] >= thr);
-      keep += pass ? 1 : 0;
+    for (int e = 0; e < CAP; ++e) keep += ((e < cnt) && (k[e] >= thr)) ? 1 : 0;
+    if (keep >= CAP) {           // crowded: every slot is inside the band -> lossy truncation
+      keep = CAP - 4;
+      lost = fmaxf(lost, k[CAP - 4]);   // sorted descending: the best entry being dropped
+      thr = fmaxf(thr, lost);
     }
-    if (EXACT) {
-      if (keep > kk) keep = kk;  // own top-kk by the total order is all the union can need
-    } else if (keep > CAP - 2) {
-      overflow = 1;              // too many columns inside the margin: the row is rescanned exactly
-      keep = CAP - 2;
-    }
-#pragma unroll
-    for (int e = 0; e < CAP; ++e) {
-      if (e < keep) { keys[e * NT] = k[e]; ids[e * NT] = id[e]; }
-    }
-    cnt = keep;
+    cnt = keep;                  // the list in LDS is sorted: truncation is just the count
   }
 
   // CAP > 16 (large k, rare): ranks by counting straight out of LDS; the partner's list is read in
@@ -243,9 +287,12 @@ struct LaneList {
         ++w;
       }
     }
-    if (!EXACT && w > CAP - 2) {
-      overflow = 1;
-      w = CAP - 2;
+    if (!EXACT && w >= CAP) {    // crowded (see finish()): keep the first CAP-4, remember the best dropped
+      float best_dropped = kNegInf;
+      for (int e = CAP - 4; e < w; ++e) best_dropped = fmaxf(best_dropped, keys[e * NT]);
+      lost = fmaxf(lost, best_dropped);
+      thr = fmaxf(thr, lost);
+      w = CAP - 4;
     }
     cnt = w;
   }

@@ -75,8 +75,9 @@ inline size_t dtype_size(int dt) { return dt == MMF_F32 ? 4 : 2; }
 // ------------------------------------------------------------------------------------------------
 
 // mmf_prep.hip: canonical squared norms (or clamped norms for cosine) of every row.
+// max_n (optional, device u32 holding float bits, zeroed by the caller) receives the largest n_i.
 int launch_row_scalars(const void* X, int64_t n, int64_t d, int dtype, int metric, float* out,
-                       hipStream_t s);
+                       uint32_t* max_n, hipStream_t s);
 
 // candidate lists written by the scan kernels and read by the select kernel:
 //   cnt[(row * lists + l)]            number of ids in list l of the row

@@ -13,7 +13,8 @@ constexpr int PREP_WAVES = 4;
 
 __global__ __launch_bounds__(64 * PREP_WAVES) void row_scalars_kernel(const void* __restrict__ X, int64_t n,
                                                                         int64_t d, int dtype, int metric,
-                                                                        float* __restrict__ out) {
+                                                                        float* __restrict__ out,
+                                                                        uint32_t* __restrict__ max_n) {
   __shared__ float tile[PREP_WAVES][64][65];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -38,14 +39,21 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void row_scalars_kernel(const void
   }
   const int64_t row = row0 + lane;
   if (row < n) out[row] = (metric == MMF_COSINE) ? clamped_norm(acc) : acc;
+  if (max_n) {  // largest squared norm (non-negative floats order like their bits); NaN never wins
+    float m = (row < n && acc == acc) ? acc : 0.0f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0 && m > 0.0f) atomicMax(max_n, __float_as_uint(m));
+  }
 }
 
-int launch_row_scalars(const void* X, int64_t n, int64_t d, int dtype, int metric, float* out, hipStream_t s) {
+int launch_row_scalars(const void* X, int64_t n, int64_t d, int dtype, int metric, float* out, uint32_t* max_n,
+                       hipStream_t s) {
   if (n <= 0) return MMF_OK;
   const int64_t rows_per_block = 64 * PREP_WAVES;
   const int64_t grid = (n + rows_per_block - 1) / rows_per_block;
   hipLaunchKernelGGL(row_scalars_kernel, dim3((unsigned)grid), dim3(64 * PREP_WAVES), 0, s, X, n, d, dtype,
-                     metric, out);
+                     metric, out, max_n);
   MMF_LAUNCH_CHECK();
   return MMF_OK;
 }

@@ -1,5 +1,402 @@
-// mmf_scan_bf16.hip — placeholder until the bf16 MFMA scan lands (this file is replaced next).
+// mmf_scan_bf16.hip — the fast all-pairs scan: bf16 / f16 MFMA candidate generation with a proven
+// error margin; the exact f32 re-rank (mmf_select.hip) turns the candidates into the final rows.
+//
+// Shape of the work: like a flash-attention S = Q K^T pass with head dim d and no
+// softmax/PV.  A workgroup = 8 waves owns 256 queries for its whole column range:
+//   * each wave keeps its 32 queries RESIDENT IN REGISTERS as the MFMA B operand
+//     (KS x bf16x8 = 128 VGPRs at d = 512), loaded once;
+//   * candidate tiles of 32 rows x d stream HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, one
+//     1 KiB piece per wave instruction), 3 stages, ONE s_barrier per tile, counted vmcnt;
+//   * the LDS image is the candidates' natural row-major layout with the 16-byte chunk index XORed
+//     by (row & 15) — applied on the DMA *source* address, LDS stays lane-linear — so every
+//     ds_read_b128 of an A fragment is bank-conflict free;
+//   * v_mfma_f32_32x32x16_{bf16,f16}: C rows = candidates, C columns = queries, so a lane holds ONE
+//     query and 16 candidates per tile; the accumulator is initialised with the per-candidate bias
+//     (-n_j/2 for the L2 metrics, -inf for padding) instead of zero, which costs nothing;
+//   * epilogue per tile: 8 v_max3 + 1 compare; only a hit enters the lane-private list code.
+//
+// Error margin: with u the f32 rows (normalised for cosine), z = round_bf16(u), the scanned value
+// G = bias_j + z_i.z_j differs from the real-number target Q = bias_j + u_i.u_j by at most
+//   E1_i = |dz_i| max|z_j| + |u_i| max|dz_j| + (DP+8) 2^-24 (|z_i| max|z_j| + max|bias|)
+// and the canonical f32 key (mapped to Q units) differs from Q by at most E2_i (rounding of the
+// chain and of the metric's few f32 ops).  Every column that can be in the canonical top-k has
+// G >= (k-th best G) - 2(E1+E2); the lists keep exactly those, so the re-rank sees a superset.
+// A list that cannot hold them (too many near-ties) flags the row; it is rescanned by the exact kernel.
+#include "mmf_dev.h"
 #include "mmf_host.h"
+
 namespace mmf {
-int scan_bf16_supported(int64_t, int, int) { return 0; }
+
+constexpr int B_NT = 512;
+constexpr int B_WAVES = 8;
+constexpr int B_QT = 256;
+constexpr int B_CT = 32;
+constexpr int B_STAGES = 3;
+constexpr int B_CAP = 12;
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// prep: z = round(u) in bf16/f16, per-row norms of z, of the rounding residual and of u, bias,
+// and the column-side maxima the margins need.  One wave per row.
+// ------------------------------------------------------------------------------------------------
+struct PrepArgs {
+  const void* X; int64_t n; int64_t d; int dtype; int metric;
+  const float* scal;        // canonical row scalars (n_i, or clamped norm for cosine)
+  const uint32_t* max_n;    // float bits of the largest n over both operands (unused for cosine)
+  void* Z; int64_t n_pad; int dp; int z_f16;
+  float* zn; float* rn; float* un; float* cb;
+  uint32_t* maxima;         // [4] float bits: max zn, max rn, max un, max |cb|
+};
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+__global__ __launch_bounds__(256) void prep_half_kernel(PrepArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.n_pad) return;
+  uint16_t* zrow = reinterpret_cast<uint16_t*>(a.Z) + row * a.dp;
+  if (row >= a.n) {  // padding rows: zeros, bias -inf so they can never be candidates
+    for (int k = lane; k < a.dp; k += 64) zrow[k] = 0;
+    if (lane == 0) { a.zn[row] = 0.f; a.rn[row] = 0.f; a.un[row] = 0.f; a.cb[row] = kNegInf; }
+    return;
+  }
+  const float sc = a.scal[row];
+  // Common exact power-of-two scale: the largest row norm lands in [256, 512), so f16 keeps its full
+  // 11-bit precision on typical elements and cannot overflow.  Scaling by 2^e is exact, it multiplies
+  // every scanned value by 2^(2e) and leaves the ranking untouched; the margins are computed from the
+  // scaled norms, so they carry the same factor.
+  float scale;
+  {
+    float mx = (a.metric == MMF_COSINE) ? 1.0f : __builtin_sqrtf(__uint_as_float(a.max_n[0]));
+    int ex = 0;
+    if (mx > 0.0f && mx < __builtin_huge_valf()) (void)frexpf(mx, &ex); else ex = 9;
+    int e = 9 - ex;
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    scale = ldexpf(1.0f, e);
+  }
+  float s_z = 0.f, s_r = 0.f, s_u = 0.f;
+  for (int k = lane; k < a.dp; k += 64) {
+    float u = 0.f;
+    if (k < a.d) {
+      u = ld_elem(a.X, row * a.d + k, a.dtype);
+      if (a.metric == MMF_COSINE) u = u / sc;
+      u = u * scale;
+    }
+    float z;
+    uint16_t bits;
+    if (a.z_f16) {
+      const _Float16 hz = (_Float16)u;
+      z = (float)hz;
+      bits = __builtin_bit_cast(uint16_t, hz);
+    } else {
+      bits = f32_to_bf16_rne(u);
+      z = bf16_bits_to_f32(bits);
+    }
+    zrow[k] = bits;
+    const float r = z - u;
+    s_z = __builtin_fmaf(z, z, s_z);
+    s_r = __builtin_fmaf(r, r, s_r);
+    s_u = __builtin_fmaf(u, u, s_u);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s_z += __shfl_xor(s_z, o);
+    s_r += __shfl_xor(s_r, o);
+    s_u += __shfl_xor(s_u, o);
+  }
+  if (lane == 0) {
+    const float up = 1.0f + 1e-4f;  // covers the rounding of these sums and square roots
+    const float zn = __builtin_sqrtf(s_z) * up, rn = __builtin_sqrtf(s_r) * up, un = __builtin_sqrtf(s_u) * up;
+    const float cb = (a.metric == MMF_NEG_SQ_L2 || a.metric == MMF_RBF) ? (-0.5f * sc * scale * scale) : 0.0f;
+    a.zn[row] = zn; a.rn[row] = rn; a.un[row] = un; a.cb[row] = cb;
+    atomicMax(a.maxima + 0, __float_as_uint(zn));   // non-negative floats order like their bits
+    atomicMax(a.maxima + 1, __float_as_uint(rn));
+    atomicMax(a.maxima + 2, __float_as_uint(un));
+    atomicMax(a.maxima + 3, __float_as_uint(fabsf(cb)));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scan
+// ------------------------------------------------------------------------------------------------
+struct ScanB16Args {
+  const void* ZQ;            // [nq_pad][DP] query side
+  const void* ZC;            // [m_pad][DP]  candidate side
+  const float* cb;           // [m_pad]
+  const float* q_zn; const float* q_rn; const float* q_un;
+  const uint32_t* maxima;    // candidate-side maxima
+  int64_t n_rows;            // queries
+  int64_t m;                 // real candidates
+  int64_t tiles_total;       // m_pad / 32
+  int64_t tiles_per_split;
+  int64_t row_blocks;
+  int col_splits;            // power of two
+  int kk;
+  int metric;
+  int d;
+  uint32_t* cand_cnt; uint32_t* cand_ids; uint32_t* overflow;
+};
+
+#define MMF_GLDS(gptr, lptr, size) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), \
+                                   (__attribute__((address_space(3))) void*)(lptr), size, 0, 0)
+
+template <int KS, bool F16>
+__global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
+  constexpr int ROWB = KS * 32;                 // bytes per candidate row in LDS (= DP * 2)
+  constexpr int TILEB = B_CT * ROWB;            // bytes per tile
+  constexpr int PIECES = TILEB / 1024;          // 1 KiB DMA pieces per tile (= KS)
+  constexpr int PPW = (PIECES + B_WAVES - 1) / B_WAVES;
+  static_assert(PIECES % B_WAVES == 0 || PIECES < B_WAVES, "piece distribution");
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  char* tiles = smem;                                                  // [B_STAGES][TILEB]
+  float* cbs = reinterpret_cast<float*>(smem + B_STAGES * TILEB);      // [B_STAGES][64]
+  float* lkeys = cbs + B_STAGES * 64;                                  // [B_CAP][B_NT]
+  uint32_t* lids = reinterpret_cast<uint32_t*>(lkeys + B_CAP * B_NT);  // [B_CAP][B_NT]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int c = lane & 31;
+
+  // XCD-aware block -> (row block, split): blocks that share blockIdx % 8 share an XCD (observed
+  // round-robin placement; speed only) and are given the same column range, so its tiles are L2 hits.
+  int64_t rb;
+  int split;
+  {
+    const int S = a.col_splits;
+    const int64_t q = blockIdx.x >> 3;
+    const int x = blockIdx.x & 7;
+    if (S <= 8) { split = x % S; rb = q * (8 / S) + x / S; }
+    else { const int g = S >> 3; split = x + 8 * (int)(q % g); rb = q / g; }
+  }
+  if (rb >= a.row_blocks) return;
+  const int64_t q0 = rb * B_QT;
+  int64_t t_begin = (int64_t)split * a.tiles_per_split;
+  int64_t t_end = t_begin + a.tiles_per_split;
+  if (t_end > a.tiles_total) t_end = a.tiles_total;
+  if (t_begin > t_end) t_begin = t_end;
+  const int64_t T = t_end - t_begin;
+
+  const int64_t qpos = q0 + 32 * wave + c;
+  const bool qvalid = qpos < a.n_rows;
+
+  // margin of this lane's query (see the header): 2 (E1 + E2)
+  float margin;
+  {
+    const float ZB = __uint_as_float(a.maxima[0]), RB = __uint_as_float(a.maxima[1]);
+    const float UB = __uint_as_float(a.maxima[2]), CB = __uint_as_float(a.maxima[3]);
+    const float zn = a.q_zn[qpos], rn = a.q_rn[qpos], un = a.q_un[qpos];   // arrays are padded
+    const float g_acc = (float)(KS * 16 + 8) * 5.9604645e-8f;
+    const float g_chain = (float)(a.d + 2) * 5.9604645e-8f;
+    const float e1 = rn * ZB + un * RB + g_acc * (zn * ZB + CB);
+    float e2;
+    if (a.metric == MMF_DOT) e2 = g_chain * un * UB;
+    else if (a.metric == MMF_COSINE) e2 = (g_chain + 4.7683716e-7f) * un * UB * 1.01f;
+    else e2 = g_chain * un * UB + 2.3841858e-7f * (un * un + UB * UB);
+    margin = 2.0f * (e1 + e2) * 1.001f + 1e-30f;
+  }
+
+  LaneList<B_CAP, B_NT> list;
+  list.init(lkeys + tid, lids + tid);
+  if (!qvalid) list.thr = __builtin_huge_valf();
+
+  // resident query fragments: B operand, lane (c, half) holds Z[q0 + 32w + c][16 s + 8 half .. +7]
+  u32x4 qf[KS];
+  {
+    const char* qb = reinterpret_cast<const char*>(a.ZQ) + (q0 + 32 * wave + c) * (int64_t)ROWB + half * 16;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const u32x4*>(qb + s * 32);
+    // make the compiler retire these loads HERE: otherwise it cannot prove them complete at their
+    // first use inside the tile loop and puts s_waitcnt vmcnt(0) there, which drains the tile DMA
+    // in flight on every iteration
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[s]));
+  }
+
+  // A-fragment read offsets inside a tile: row c, chunk (2s + half) ^ (c & 15)
+  int lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) lo[j] = c * ROWB + ((((2 * j + half) ^ (c & 15)) & 15) << 4);
+
+  // DMA roles: piece p of a tile covers LDS bytes [1024 p, 1024 p + 1024); lane writes 16 B at l*16.
+  // Source = uniform tile base + a loop-invariant 32-bit lane offset (keeps the address in
+  // SGPR base + VGPR offset form: 1 VGPR per piece instead of a 64-bit pointer pair).
+  const char* zc = reinterpret_cast<const char*>(a.ZC);
+  uint32_t src_off[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int p = wave + B_WAVES * i;
+    const int off = p * 1024 + lane * 16;
+    const int r = off / ROWB;
+    const int chunk = (off % ROWB) >> 4;
+    const int src_chunk = (chunk & ~15) | ((chunk ^ r) & 15);
+    src_off[i] = (uint32_t)(r * ROWB + src_chunk * 16);
+  }
+  auto issue_tile = [&](int64_t t, int stage) {
+    const char* tsrc = zc + (t_begin + t) * (int64_t)TILEB;   // wave-uniform
+    char* tb = tiles + stage * TILEB;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) MMF_GLDS(tsrc + src_off[i], tb + (wave + B_WAVES * i) * 1024, 16);
+  };
+  // the 32 biases of a tile: one 4-byte DMA by lanes 0..31 of the wave whose turn it is
+  const uint32_t lane4 = (uint32_t)lane * 4u;
+  auto issue_bias = [&](int64_t t, int stage) {
+    const char* bsrc = reinterpret_cast<const char*>(a.cb + (t_begin + t) * B_CT);   // wave-uniform
+    if (lane < 32) MMF_GLDS(bsrc + lane4, cbs + stage * 64, 4);
+  };
+  auto bias_wave = [&](int64_t t) { return (int)(t & 7); };
+
+  if (T > 0) {
+    issue_tile(0, 0);
+    if (wave == bias_wave(0)) issue_bias(0, 0);
+    if (T > 1) {
+      issue_tile(1, 1);
+      if (wave == bias_wave(1)) issue_bias(1, 1);
+    }
+  }
+
+  int stage = 0;
+  for (int64_t t = 0; t < T; ++t) {
+    // my pieces of tile t have landed once at most the pieces of tile t+1 are outstanding
+    {
+      const bool next = (t + 1 < T);
+      const int extra = (next && wave == bias_wave(t + 1)) ? 1 : 0;
+      const int allow = next ? (((PIECES >= B_WAVES) || (wave < PIECES)) ? PPW : 0) + extra : 0;
+      // vmcnt(N) alone: expcnt = 7 and lgkmcnt = 15 mean "no wait" (gfx9 encoding)
+      if (allow == 0) __builtin_amdgcn_s_waitcnt(0x0F70);
+      else if (allow == 1) __builtin_amdgcn_s_waitcnt(0x0F71);
+      else if (allow == 2) __builtin_amdgcn_s_waitcnt(0x0F72);
+      else if (allow == 3) __builtin_amdgcn_s_waitcnt(0x0F73);
+      else if (allow == 4) __builtin_amdgcn_s_waitcnt(0x0F74);
+      else __builtin_amdgcn_s_waitcnt(0x0F75);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // tile t visible to all; everyone is done with tile t-1
+    asm volatile("" ::: "memory");
+    if (t + 2 < T) {
+      int s2 = stage + 2;
+      if (s2 >= B_STAGES) s2 -= B_STAGES;
+      issue_tile(t + 2, s2);
+      if (wave == bias_wave(t + 2)) issue_bias(t + 2, s2);
+    }
+
+    const char* tb = tiles + stage * TILEB;
+    const float* cbt = cbs + stage * 64;
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(cbt + 8 * g + 4 * half);
+      acc[4 * g + 0] = b4[0]; acc[4 * g + 1] = b4[1]; acc[4 * g + 2] = b4[2]; acc[4 * g + 3] = b4[3];
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const u32x4 af = *reinterpret_cast<const u32x4*>(tb + lo[s & 7] + (s >> 3) * 256);
+      if constexpr (F16)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, af), __builtin_bit_cast(f16x8_t, qf[s]), acc, 0, 0, 0);
+      else
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, qf[s]), acc, 0, 0, 0);
+    }
+
+    const float mx = max16(acc);
+    if (__any(mx >= list.thr))
+      list.template offer_tile<false>(acc, (uint32_t)((t_begin + t) * B_CT), half, a.kk, margin);
+
+    ++stage;
+    if (stage == B_STAGES) stage = 0;
+  }
+
+  list.template compact<false>(a.kk, margin);
+  list.finish();
+  if (qvalid) {
+    const int64_t lbase = qpos * (2 * a.col_splits) + 2 * split + half;
+    a.cand_cnt[lbase] = (uint32_t)list.cnt;
+    for (int e = 0; e < list.cnt; ++e) a.cand_ids[lbase * B_CAP + e] = list.ids[e * B_NT];
+    if (list.overflow) atomicOr(a.overflow + qpos, 1u);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int pad_dp(int64_t d) {
+  if (d <= 128) return 128;
+  if (d <= 256) return 256;
+  if (d <= 512) return 512;
+  return 0;
+}
+
+int scan_bf16_supported(int64_t d, int kk, int dtype) {
+  (void)dtype;
+  return (pad_dp(d) != 0 && kk <= B_CAP - 4) ? 1 : 0;
+}
+
+int scan_bf16_cap() { return B_CAP; }
+int scan_bf16_dp(int64_t d) { return pad_dp(d); }
+
+int launch_prep_half(const void* X, int64_t n, int64_t d, int dtype, int metric, const float* scal,
+                     const uint32_t* max_n, void* Z, int64_t n_pad, int dp, int z_f16, float* zn, float* rn,
+                     float* un, float* cb, uint32_t* maxima, hipStream_t s) {
+  PrepArgs a{X, n, d, dtype, metric, scal, max_n, Z, n_pad, dp, z_f16, zn, rn, un, cb, maxima};
+  hipLaunchKernelGGL(prep_half_kernel, dim3((unsigned)((n_pad + 3) / 4)), dim3(256), 0, s, a);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+
+static size_t scan_b16_lds(int ks) {
+  return (size_t)B_STAGES * (B_CT * ks * 32) + (size_t)B_STAGES * 64 * 4 + (size_t)B_CAP * B_NT * 8;
+}
+
+template <int KS>
+static int launch_b16_t(const ScanB16Args& a, bool f16, int64_t grid, hipStream_t s) {
+  const size_t lds = scan_b16_lds(KS);
+  auto go = [&](auto kern) -> int {
+    MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(B_NT), lds, s, a);
+    MMF_LAUNCH_CHECK();
+    return MMF_OK;
+  };
+  if (f16) return go(scan_b16_kernel<KS, true>);
+  return go(scan_b16_kernel<KS, false>);
+}
+
+// col_splits must be a power of two.  Lists are indexed by query position, cap = B_CAP.
+int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float* q_zn, const float* q_rn,
+                    const float* q_un, const uint32_t* maxima, int64_t n_rows, int64_t m, int64_t m_pad, int dp,
+                    int64_t d, bool f16, int metric, int kk, int col_splits, const CandLists& L, hipStream_t s,
+                    int* grid_out) {
+  ScanB16Args a{};
+  a.ZQ = ZQ; a.ZC = ZC; a.cb = cb; a.q_zn = q_zn; a.q_rn = q_rn; a.q_un = q_un; a.maxima = maxima;
+  a.n_rows = n_rows; a.m = m; a.tiles_total = m_pad / B_CT;
+  a.tiles_per_split = (a.tiles_total + col_splits - 1) / col_splits;
+  a.row_blocks = (n_rows + B_QT - 1) / B_QT;
+  a.col_splits = col_splits; a.kk = kk; a.metric = metric; a.d = (int)d;
+  a.cand_cnt = L.cnt; a.cand_ids = L.ids; a.overflow = L.overflow;
+  int64_t blocks = a.row_blocks * col_splits;
+  int64_t grid;
+  if (col_splits <= 8) {
+    const int per = 8 / col_splits;                       // row blocks per group of 8 block ids
+    grid = ((a.row_blocks + per - 1) / per) * 8;
+  } else {
+    grid = blocks;                                        // col_splits multiple of 8: exact
+  }
+  if (grid_out) *grid_out = (int)grid;
+  switch (dp) {
+    case 128: return launch_b16_t<8>(a, f16, grid, s);
+    case 256: return launch_b16_t<16>(a, f16, grid, s);
+    case 512: return launch_b16_t<32>(a, f16, grid, s);
+  }
+  set_error("scan_b16: unsupported padded dim %d", dp);
+  return MMF_E_INTERNAL;
+}
+
 }  // namespace mmf

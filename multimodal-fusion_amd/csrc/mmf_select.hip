@@ -61,6 +61,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_kernel(SelectArgs a) {
   uint32_t* id = sid[wave];
 
   bool failed = a.overflow[pos] != 0;
+  const bool was_overflow = failed;
   int total = 0;
   if (!failed) {
     for (int l = 0; l < a.lists; ++l) {
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_kernel(SelectArgs a) {
     if (lane == 0) {
       const uint32_t slot = atomicAdd(a.fail_count, 1u);
       a.fail_rows[slot] = (int32_t)pos;
+      atomicAdd(a.fail_count + (was_overflow ? 1 : 2), 1u);   // reason counters (stats only)
     }
     return;
   }

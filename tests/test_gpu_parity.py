@@ -71,6 +71,66 @@ def test_simtopk_self_exact(mmf, metric, n, d, k):
     check_topk(mmf, X, None, metric, k, lam=1.0)
 
 
+# the bf16 MFMA scan + exact re-rank must give the SAME bits as the exact scan and the oracle
+@pytest.mark.parametrize("metric", ["dot", "cosine", "neg_sq_l2", "rbf"])
+@pytest.mark.parametrize("n,d,k", [(2, 4, 1), (33, 3, 5), (300, 32, 5), (1000, 128, 7), (257, 100, 7), (2049, 512, 5),
+                                   (5000, 256, 5), (777, 500, 3)])
+def test_simtopk_self_fast(mmf, metric, n, d, k):
+    X = unit_rows(n, d, 10 + n).numpy() if d > 3 else rnd(n, d, 5)
+    check_topk(mmf, X, None, metric, k, lam=1.0, precision="fast")
+    check_topk(mmf, X, None, metric, k, lam=1.0, precision="fast_bf16")
+
+
+def test_simtopk_fast_extreme_scales(mmf):
+    # the exact power-of-two scale of the f16 operands must cope with tiny and huge row norms
+    for scale in (1e-20, 1e-6, 1e4, 1e15):
+        X = rnd(700, 96, 41) * np.float32(scale)
+        for metric in ("dot", "cosine", "neg_sq_l2"):
+            check_topk(mmf, X, None, metric, 4, precision="fast")
+    X = rnd(600, 64, 42)
+    X[::7] *= 1e-4            # mixed norms: small rows get a wide margin, must still be exact
+    X[5] = 0.0
+    for metric in ("dot", "cosine", "neg_sq_l2"):
+        check_topk(mmf, X, None, metric, 4, precision="fast")
+
+
+def test_simtopk_fast_unnormalised_and_rect(mmf):
+    X, Y = rnd(900, 200, 31, 3.0), rnd(2100, 200, 32, 0.05)      # very different row norms
+    for metric in ("dot", "cosine", "neg_sq_l2"):
+        check_topk(mmf, X, Y, metric, 6, precision="fast")
+        check_topk(mmf, Y, X, metric, 4, precision="fast")
+    check_topk(mmf, X * 0.02, None, "rbf", 5, lam=0.5, precision="fast")
+
+
+def test_simtopk_fast_overflow_falls_back_to_exact(mmf):
+    # 40 exact copies of 10 rows: far more columns sit inside the bf16 margin than a list can hold,
+    # so the rows are flagged and rescanned by the exact kernel; the answer must not change.
+    D = np.repeat(rnd(10, 64, 3), 40, axis=0)
+    idx, val, st = mmf.simtopk(dev(D), metric="neg_sq_l2", k=5, precision="fast", return_stats=True)
+    ridx, rval = oracle.simtopk(D, metric="neg_sq_l2", k=5)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(val.cpu().numpy(), rval)
+    assert st["precision_used"] == 2 and st["fallback_rows"] > 0 and st["overflow_rows"] == st["fallback_rows"]
+    # a tight cluster inside an otherwise random set: only the cluster's rows need the rescan
+    X = unit_rows(3000, 128, 77).numpy()
+    X[100:160] = X[100] + 1e-4 * rnd(60, 128, 78)
+    ridx, rval = oracle.simtopk(X, metric="cosine", k=5)
+    for splits in (1, 0):
+        idx, val, st = mmf.simtopk(dev(X), metric="cosine", k=5, precision="fast", col_splits=splits, return_stats=True)
+        assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(val.cpu().numpy(), rval)
+        if splits == 1:   # the 60 cluster rows (+ the few rows whose top-k touches the cluster), not the
+            assert 60 <= st["fallback_rows"] <= 120, st   # rows that only met the cluster while their threshold was low
+
+
+def test_simtopk_fast_forced_splits_and_offsets(mmf):
+    X = unit_rows(4096, 128, 5).numpy()
+    full_i, full_v = oracle.simtopk(X, metric="cosine", k=5)
+    for splits in (1, 2, 8, 16):
+        i, v = mmf.simtopk(dev(X), metric="cosine", k=5, precision="fast", col_splits=splits)
+        assert np.array_equal(i.cpu().numpy(), full_i) and np.array_equal(v.cpu().numpy(), full_v), splits
+    i, v = mmf.simtopk(dev(X[1000:1777]), dev(X), metric="cosine", k=5, exclude_self=True, row_offset=1000, precision="fast")
+    assert np.array_equal(i.cpu().numpy(), full_i[1000:1777]) and np.array_equal(v.cpu().numpy(), full_v[1000:1777])
+
+
 @pytest.mark.parametrize("metric", ["cosine", "neg_sq_l2"])
 def test_simtopk_rect_exact(mmf, metric):
     X, Y = rnd(333, 96, 7), rnd(1500, 96, 8)
@@ -110,9 +170,10 @@ def test_simtopk_half_inputs(mmf):
     X = unit_rows(500, 64, 21)
     for dt in (torch.bfloat16, torch.float16):
         Xh = X.to(dt)
-        idx, val = mmf.simtopk(Xh.cuda(), metric="cosine", k=5, precision="exact")
         ridx, rval = oracle.simtopk(Xh.float().numpy(), metric="cosine", k=5)
-        assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(val.cpu().numpy(), rval)
+        for prec in ("exact", "fast"):
+            idx, val = mmf.simtopk(Xh.cuda(), metric="cosine", k=5, precision=prec)
+            assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(val.cpu().numpy(), rval), (dt, prec)
 
 
 def test_golden_knn_through_gpu(mmf):
