@@ -53,14 +53,16 @@ def cpu_baseline(n: int, d: int, k: int, metric: str, device):
     cols = min(n, 65536)
     Y = make_rows(0, cols, d, device).cpu().numpy()
     threads = oracle.num_threads()
-    t0 = time.perf_counter()
-    oracle.simtopk(Y[:256], Y[:8192], metric=metric, k=k, exclude_self=True)   # warm-up + calibration
-    rate = 256 * 8192 / (time.perf_counter() - t0)
-    rows = int(max(64, min(cols, (15.0 * rate) / cols)))
-    rows -= rows % 4
-    t0 = time.perf_counter()
-    oracle.simtopk(Y[:rows], Y, metric=metric, k=k, exclude_self=True)
-    dt = time.perf_counter() - t0
+    oracle.simtopk(Y[:64], Y[:4096], metric=metric, k=k, exclude_self=True)        # thread pool start-up
+    rows, dt = 512, 0.0
+    while True:                                                                     # grow until ~10 s
+        t0 = time.perf_counter()
+        oracle.simtopk(Y[:rows], Y, metric=metric, k=k, exclude_self=True)
+        dt = time.perf_counter() - t0
+        if dt >= 8.0 or rows >= cols:
+            break
+        rows = int(min(cols, max(rows * 2, rows * 10.0 / max(dt, 1e-3))))
+        rows -= rows % 4
     return {"value": rows * cols / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
             "sample": f"{rows} query rows x {cols} columns of the same workload (d={d}, {metric}, k={k}), "
                       f"oracle/mmf_oracle.c with {threads} OpenMP threads, {dt:.1f} s"}

@@ -60,15 +60,6 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
 
 __global__ __launch_bounds__(256) void prep_half_kernel(PrepArgs a) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.n_pad) return;
-  uint16_t* zrow = reinterpret_cast<uint16_t*>(a.Z) + row * a.dp;
-  if (row >= a.n) {  // padding rows: zeros, bias -inf so they can never be candidates
-    for (int k = lane; k < a.dp; k += 64) zrow[k] = 0;
-    if (lane == 0) { a.zn[row] = 0.f; a.rn[row] = 0.f; a.un[row] = 0.f; a.cb[row] = kNegInf; }
-    return;
-  }
-  const float sc = a.scal[row];
   // Common exact power-of-two scale: the largest row norm lands in [256, 512), so f16 keeps its full
   // 11-bit precision on typical elements and cannot overflow.  Scaling by 2^e is exact, it multiplies
   // every scanned value by 2^(2e) and leaves the ranking untouched; the margins are computed from the
@@ -82,45 +73,60 @@ __global__ __launch_bounds__(256) void prep_half_kernel(PrepArgs a) {
     e = e < -100 ? -100 : (e > 100 ? 100 : e);
     scale = ldexpf(1.0f, e);
   }
-  float s_z = 0.f, s_r = 0.f, s_u = 0.f;
-  for (int k = lane; k < a.dp; k += 64) {
-    float u = 0.f;
-    if (k < a.d) {
-      u = ld_elem(a.X, row * a.d + k, a.dtype);
-      if (a.metric == MMF_COSINE) u = u / sc;
-      u = u * scale;
+  // one wave per row, grid-stride over rows; the four column-side maxima are kept per wave and
+  // published once at the end (a same-address atomic per row would serialise the whole kernel)
+  float m_zn = 0.f, m_rn = 0.f, m_un = 0.f, m_cb = 0.f;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t row = wave0; row < a.n_pad; row += nwaves) {
+    uint16_t* zrow = reinterpret_cast<uint16_t*>(a.Z) + row * a.dp;
+    if (row >= a.n) {  // padding rows: zeros, bias -inf so they can never be candidates
+      for (int k = lane; k < a.dp; k += 64) zrow[k] = 0;
+      if (lane == 0) { a.zn[row] = 0.f; a.rn[row] = 0.f; a.un[row] = 0.f; a.cb[row] = kNegInf; }
+      continue;
     }
-    float z;
-    uint16_t bits;
-    if (a.z_f16) {
-      const _Float16 hz = (_Float16)u;
-      z = (float)hz;
-      bits = __builtin_bit_cast(uint16_t, hz);
-    } else {
-      bits = f32_to_bf16_rne(u);
-      z = bf16_bits_to_f32(bits);
+    const float sc = a.scal[row];
+    float s_z = 0.f, s_r = 0.f, s_u = 0.f;
+    for (int k = lane; k < a.dp; k += 64) {
+      float u = 0.f;
+      if (k < a.d) {
+        u = ld_elem(a.X, row * a.d + k, a.dtype);
+        if (a.metric == MMF_COSINE) u = u / sc;
+        u = u * scale;
+      }
+      float z;
+      uint16_t bits;
+      if (a.z_f16) {
+        const _Float16 hz = (_Float16)u;
+        z = (float)hz;
+        bits = __builtin_bit_cast(uint16_t, hz);
+      } else {
+        bits = f32_to_bf16_rne(u);
+        z = bf16_bits_to_f32(bits);
+      }
+      zrow[k] = bits;
+      const float r = z - u;
+      s_z = __builtin_fmaf(z, z, s_z);
+      s_r = __builtin_fmaf(r, r, s_r);
+      s_u = __builtin_fmaf(u, u, s_u);
     }
-    zrow[k] = bits;
-    const float r = z - u;
-    s_z = __builtin_fmaf(z, z, s_z);
-    s_r = __builtin_fmaf(r, r, s_r);
-    s_u = __builtin_fmaf(u, u, s_u);
-  }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s_z += __shfl_xor(s_z, o);
-    s_r += __shfl_xor(s_r, o);
-    s_u += __shfl_xor(s_u, o);
-  }
-  if (lane == 0) {
+    for (int o = 32; o > 0; o >>= 1) {
+      s_z += __shfl_xor(s_z, o);
+      s_r += __shfl_xor(s_r, o);
+      s_u += __shfl_xor(s_u, o);
+    }
     const float up = 1.0f + 1e-4f;  // covers the rounding of these sums and square roots
     const float zn = __builtin_sqrtf(s_z) * up, rn = __builtin_sqrtf(s_r) * up, un = __builtin_sqrtf(s_u) * up;
     const float cb = (a.metric == MMF_NEG_SQ_L2 || a.metric == MMF_RBF) ? (-0.5f * sc * scale * scale) : 0.0f;
-    a.zn[row] = zn; a.rn[row] = rn; a.un[row] = un; a.cb[row] = cb;
-    atomicMax(a.maxima + 0, __float_as_uint(zn));   // non-negative floats order like their bits
-    atomicMax(a.maxima + 1, __float_as_uint(rn));
-    atomicMax(a.maxima + 2, __float_as_uint(un));
-    atomicMax(a.maxima + 3, __float_as_uint(fabsf(cb)));
+    if (lane == 0) { a.zn[row] = zn; a.rn[row] = rn; a.un[row] = un; a.cb[row] = cb; }
+    m_zn = fmaxf(m_zn, zn); m_rn = fmaxf(m_rn, rn); m_un = fmaxf(m_un, un); m_cb = fmaxf(m_cb, fabsf(cb));
+  }
+  if (lane == 0) {   // non-negative floats order like their bits
+    if (m_zn > 0.f) atomicMax(a.maxima + 0, __float_as_uint(m_zn));
+    if (m_rn > 0.f) atomicMax(a.maxima + 1, __float_as_uint(m_rn));
+    if (m_un > 0.f) atomicMax(a.maxima + 2, __float_as_uint(m_un));
+    if (m_cb > 0.f) atomicMax(a.maxima + 3, __float_as_uint(m_cb));
   }
 }
 
@@ -347,7 +353,9 @@ int launch_prep_half(const void* X, int64_t n, int64_t d, int dtype, int metric,
                      const uint32_t* max_n, void* Z, int64_t n_pad, int dp, int z_f16, float* zn, float* rn,
                      float* un, float* cb, uint32_t* maxima, hipStream_t s) {
   PrepArgs a{X, n, d, dtype, metric, scal, max_n, Z, n_pad, dp, z_f16, zn, rn, un, cb, maxima};
-  hipLaunchKernelGGL(prep_half_kernel, dim3((unsigned)((n_pad + 3) / 4)), dim3(256), 0, s, a);
+  int64_t grid = (n_pad + 3) / 4;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(prep_half_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
   MMF_LAUNCH_CHECK();
   return MMF_OK;
 }

@@ -207,6 +207,22 @@ def main() -> None:
                         pool1=sk.mean_pool_with_similarity(X).numpy(),
                         pool2=sk2.mean_pool_with_similarity(X, P, 1.0, 1.0).numpy())
 
+    # ---- signatures of the boundary functions (names, order, defaults): data, not code ----------
+    import inspect
+
+    def sig(fn):
+        return [[p.name, None if p.default is inspect._empty else repr(p.default)] for p in inspect.signature(fn).parameters.values()]
+    sigs = {"build_hypergraph": {n: sig(getattr(sk, n)) for n in
+                                 ("compute_morphological_similarity", "compute_spatial_similarity", "compute_combined_similarity",
+                                  "build_weighted_hypergraph", "mean_pool_with_similarity", "build_hypergraph_data")},
+            "hypergraph.build_hypergraph": {n: sig(getattr(sk2, n)) for n in
+                                            ("compute_morphological_similarity", "compute_spatial_similarity",
+                                             "compute_combined_similarity", "build_weighted_hypergraph",
+                                             "mean_pool_with_similarity", "build_hypergraph_data")}}
+    sigs["build_hypergraph"].update({n: sig(pp[n]) for n in pp})
+    with open(os.path.join(OUT, "signatures.json"), "w") as fh:
+        json.dump(sigs, fh, indent=1, sort_keys=True)
+
     meta = {"generator": "tests/golden/make_golden.py", "reference": "zz9tf/multimodal-fusion @ 2026-01-30",
             "torch": torch.__version__, "numpy": np.__version__, "sklearn": sklearn.__version__,
             "python": sys.version.split()[0], "torch_threads": torch.get_num_threads()}
