@@ -173,59 +173,78 @@ struct LaneList {
     if (nthr > thr) thr = nthr;
   }
 
-  // CAP <= 16: both lists sorted in registers by a bitonic network, merged with the partner's.
+  // CAP <= 16.
   template <bool EXACT>
   __device__ __forceinline__ void compact_sorted(int kk, float margin) {
+    if constexpr (EXACT) compact_pairs(kk);
+    else compact_keys(kk, margin);
+  }
+
+  // Final keys (exact scan): the merge must break key ties by id, so (key, id) pairs are sorted in
+  // registers by a bitonic network and merged with the partner lane's.
+  __device__ __forceinline__ void compact_pairs(int kk) {
     float k[SORTN];
-    {
-      uint32_t id[SORTN];
+    uint32_t id[SORTN];
 #pragma unroll
-      for (int e = 0; e < SORTN; ++e) {
-        const bool live = (e < CAP) && (e < cnt);
-        k[e] = live ? keys[(e < CAP ? e : 0) * NT] : kNegInf;
-        id[e] = live ? ids[(e < CAP ? e : 0) * NT] : kNoIdx;
-      }
-      sort_desc<SORTN>(k, id);
-      if constexpr (!EXACT) {
-        // approximate keys: only the KEY order matters from here on; park the sorted list in LDS
-        // now so the ids leave the registers before the merge (register pressure: 128 VGPRs of
-        // resident query fragments live across this code in the bf16 kernel)
+    for (int e = 0; e < SORTN; ++e) {
+      const bool live = (e < CAP) && (e < cnt);
+      k[e] = live ? keys[(e < CAP ? e : 0) * NT] : kNegInf;
+      id[e] = live ? ids[(e < CAP ? e : 0) * NT] : kNoIdx;
+    }
+    sort_desc<SORTN>(k, id);
+    // top SORTN of the union with the partner lane (same query, other half of every tile):
+    // c[i] = best(a[i], b[SORTN-1-i]) is the bitonic partition of two descending lists.
+    float c[SORTN];
+    uint32_t ci[SORTN];
 #pragma unroll
-        for (int e = 0; e < CAP; ++e) { keys[e * NT] = k[e]; ids[e * NT] = id[e]; }
-      } else {
-        // final keys: the merge must break key ties by id, keep the pairs
-        float c[SORTN];
-        uint32_t ci[SORTN];
+    for (int e = 0; e < SORTN; ++e) {
+      const float pk = __shfl_xor(k[SORTN - 1 - e], 32);
+      const uint32_t pi = (uint32_t)__shfl_xor((int)id[SORTN - 1 - e], 32);
+      const bool own = better(k[e], id[e], pk, pi);
+      c[e] = own ? k[e] : pk;
+      ci[e] = own ? id[e] : pi;
+    }
+    bitonic_merge_desc<SORTN>(c, ci);
+    float t = kNegInf;
 #pragma unroll
-        for (int e = 0; e < SORTN; ++e) {
-          const float pk = __shfl_xor(k[SORTN - 1 - e], 32);
-          const uint32_t pi = (uint32_t)__shfl_xor((int)id[SORTN - 1 - e], 32);
-          const bool own = better(k[e], id[e], pk, pi);
-          c[e] = own ? k[e] : pk;
-          ci[e] = own ? id[e] : pi;
+    for (int e = 0; e < SORTN; ++e) {
+      if (e == kk - 1) t = c[e];
+    }
+    raise_thr(t, 0.0f, true);
+    int keep = 0;
+#pragma unroll
+    for (int e = 0; e < CAP; ++e) keep += ((e < cnt) && (k[e] >= thr)) ? 1 : 0;
+    if (keep > kk) keep = kk;  // own top-kk by the total order is all the union can need
+#pragma unroll
+    for (int e = 0; e < CAP; ++e) {
+      if (e < keep) { keys[e * NT] = k[e]; ids[e * NT] = id[e]; }
+    }
+    cnt = keep;
+  }
+
+  // Approximate keys (16-bit scan): only the KEY order matters.  Sort the bare keys (a pure
+  // v_max/v_min network, 16 registers), take the kk-th best of the union with the partner lane,
+  // then filter the list in place in LDS.  Always leaves at least two free slots; what it has to
+  // drop for that is recorded in `lost` (see finish()).
+  __device__ __forceinline__ void compact_keys(int kk, float margin) {
+    float k[SORTN];
+#pragma unroll
+    for (int e = 0; e < SORTN; ++e) k[e] = ((e < CAP) && (e < cnt)) ? keys[(e < CAP ? e : 0) * NT] : kNegInf;
+#pragma unroll
+    for (int size = 2; size <= SORTN; size <<= 1) {
+#pragma unroll
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+        for (int i = 0; i < SORTN; ++i) {
+          const int j = i ^ stride;
+          if (j > i) {
+            const float hi = fmaxf(k[i], k[j]), lo = fminf(k[i], k[j]);
+            if ((i & size) == 0) { k[i] = hi; k[j] = lo; } else { k[i] = lo; k[j] = hi; }
+          }
         }
-        bitonic_merge_desc<SORTN>(c, ci);
-        float t = kNegInf;
-#pragma unroll
-        for (int e = 0; e < SORTN; ++e) {
-          if (e == kk - 1) t = c[e];
-        }
-        raise_thr(t, 0.0f, true);
-        int keep = 0;
-#pragma unroll
-        for (int e = 0; e < CAP; ++e) keep += ((e < cnt) && (k[e] >= thr)) ? 1 : 0;
-        if (keep > kk) keep = kk;  // own top-kk by the total order is all the union can need
-#pragma unroll
-        for (int e = 0; e < CAP; ++e) {
-          if (e < keep) { keys[e * NT] = k[e]; ids[e * NT] = id[e]; }
-        }
-        cnt = keep;
-        return;
       }
     }
-    // !EXACT: top SORTN keys of the union with the partner lane (same query, other half of every
-    // tile): c[i] = max(a[i], b[SORTN-1-i]) is the bitonic partition of two descending lists, and
-    // the merge network on bare keys is pure v_max/v_min.
+    // c[i] = max(a[i], b[SORTN-1-i]): bitonic partition of two descending lists = top SORTN of the union
     float c[SORTN];
 #pragma unroll
     for (int e = 0; e < SORTN; ++e) c[e] = fmaxf(k[e], __shfl_xor(k[SORTN - 1 - e], 32));
@@ -249,12 +268,23 @@ struct LaneList {
     int keep = 0;
 #pragma unroll
     for (int e = 0; e < CAP; ++e) keep += ((e < cnt) && (k[e] >= thr)) ? 1 : 0;
-    if (keep >= CAP) {           // crowded: every slot is inside the band -> lossy truncation
-      keep = CAP - 4;
-      lost = fmaxf(lost, k[CAP - 4]);   // sorted descending: the best entry being dropped
+    float cut = thr;
+    if (keep >= CAP - 1) {       // crowded: (nearly) every slot is inside the band -> lossy truncation
+      lost = fmaxf(lost, k[CAP - 2]);   // sorted descending: the best entry being dropped
       thr = fmaxf(thr, lost);
+      cut = k[CAP - 3];                 // keep the CAP-2 best: two free slots
     }
-    cnt = keep;                  // the list in LDS is sorted: truncation is just the count
+    int w = 0;
+    for (int e = 0; e < cnt; ++e) {     // in-place filter, lane-private
+      const float ke = keys[e * NT];
+      const uint32_t ie = ids[e * NT];
+      if (ke >= cut) {
+        if (w < CAP - 2) { keys[w * NT] = ke; ids[w * NT] = ie; ++w; }
+        else lost = fmaxf(lost, ke);    // ties at the cut beyond the guaranteed free slots
+      }
+    }
+    thr = fmaxf(thr, lost);
+    cnt = w;
   }
 
   // CAP > 16 (large k, rare): ranks by counting straight out of LDS; the partner's list is read in
@@ -287,7 +317,7 @@ struct LaneList {
         ++w;
       }
     }
-    if (!EXACT && w >= CAP) {    // crowded (see finish()): keep the first CAP-4, remember the best dropped
+    if (!EXACT && w >= CAP - 1) {  // crowded (see finish()): keep the first CAP-4, remember the best dropped
       float best_dropped = kNegInf;
       for (int e = CAP - 4; e < w; ++e) best_dropped = fmaxf(best_dropped, keys[e * NT]);
       lost = fmaxf(lost, best_dropped);
@@ -313,6 +343,26 @@ struct LaneList {
         if (hit) {
           if (cnt < CAP) push(x, id0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * half));
           else overflow = 1;
+        }
+      }
+    }
+  }
+
+  // Approximate mode, warm lists (every lane already has a real threshold): the common case of the
+  // 16-bit scan.  One compaction site ahead of the pushes guarantees two free slots per lane; the
+  // 16 registers are tested by straight-line code (no dynamic register index), and a hit that still
+  // finds its list full is dropped under the audited-loss rule (finish()), never blocks.
+  __device__ __forceinline__ void offer_tile_warm(const f32x16& v, uint32_t id0, int half, int kk, float margin) {
+    if (__any(cnt >= CAP - 1)) compact<false>(kk, margin);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float x = v[r];
+      if (x >= thr) {
+        if (cnt < CAP) {
+          push(x, id0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * half));
+        } else {
+          lost = fmaxf(lost, x);
+          thr = fmaxf(thr, lost);
         }
       }
     }

@@ -22,6 +22,10 @@
 // chain and of the metric's few f32 ops).  Every column that can be in the canonical top-k has
 // G >= (k-th best G) - 2(E1+E2); the lists keep exactly those, so the re-rank sees a superset.
 // A list that cannot hold them (too many near-ties) flags the row; it is rescanned by the exact kernel.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "mmf_dev.h"
 #include "mmf_host.h"
 
@@ -148,6 +152,8 @@ struct ScanB16Args {
   int kk;
   int metric;
   int d;
+  int debug;                 // MMF_SCAN_DEBUG: 1 = skip the filter / list code (timing only), 8 = count events
+  unsigned long long* dbg;   // [8] event counters when debug & 8
   uint32_t* cand_cnt; uint32_t* cand_ids; uint32_t* overflow;
 };
 
@@ -235,9 +241,7 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
   for (int j = 0; j < 8; ++j) lo[j] = c * ROWB + ((((2 * j + half) ^ (c & 15)) & 15) << 4);
 
   // DMA roles: piece p of a tile covers LDS bytes [1024 p, 1024 p + 1024); lane writes 16 B at l*16.
-  // Source = uniform tile base + a loop-invariant 32-bit lane offset (keeps the address in
-  // SGPR base + VGPR offset form: 1 VGPR per piece instead of a 64-bit pointer pair).
-  const char* zc = reinterpret_cast<const char*>(a.ZC);
+  // Source = wave-uniform running tile pointer + a loop-invariant 32-bit lane offset.
   uint32_t src_off[PPW];
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
@@ -248,56 +252,40 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
     const int src_chunk = (chunk & ~15) | ((chunk ^ r) & 15);
     src_off[i] = (uint32_t)(r * ROWB + src_chunk * 16);
   }
-  auto issue_tile = [&](int64_t t, int stage) {
-    const char* tsrc = zc + (t_begin + t) * (int64_t)TILEB;   // wave-uniform
-    char* tb = tiles + stage * TILEB;
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) MMF_GLDS(tsrc + src_off[i], tb + (wave + B_WAVES * i) * 1024, 16);
+  const uint32_t lane4 = (uint32_t)lane * 4u;
+  const char* zc0 = reinterpret_cast<const char*>(a.ZC) + t_begin * (int64_t)TILEB;          // tile 0 of my range
+  const char* cb0 = reinterpret_cast<const char*>(a.cb + t_begin * B_CT);
+  auto issue_piece = [&](const char* tsrc, int stage, int i) {
+    MMF_GLDS(tsrc + src_off[i], tiles + stage * TILEB + (wave + B_WAVES * i) * 1024, 16);
   };
   // the 32 biases of a tile: one 4-byte DMA by lanes 0..31 of the wave whose turn it is
-  const uint32_t lane4 = (uint32_t)lane * 4u;
-  auto issue_bias = [&](int64_t t, int stage) {
-    const char* bsrc = reinterpret_cast<const char*>(a.cb + (t_begin + t) * B_CT);   // wave-uniform
+  auto issue_bias = [&](const char* bsrc, int stage) {
     if (lane < 32) MMF_GLDS(bsrc + lane4, cbs + stage * 64, 4);
   };
-  auto bias_wave = [&](int64_t t) { return (int)(t & 7); };
 
-  if (T > 0) {
-    issue_tile(0, 0);
-    if (wave == bias_wave(0)) issue_bias(0, 0);
-    if (T > 1) {
-      issue_tile(1, 1);
-      if (wave == bias_wave(1)) issue_bias(1, 1);
-    }
+  const int Ti = (int)T;
+  if (Ti > 0) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) issue_piece(zc0, 0, i);
+    if (wave == 0) issue_bias(cb0, 0);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) issue_piece(Ti > 1 ? zc0 + TILEB : zc0, 1, i);
+    if (wave == 1) issue_bias(Ti > 1 ? cb0 + B_CT * 4 : cb0, 1);
   }
+  // The two waves that share a SIMD (w and w+4) run in lockstep after every barrier.  Issuing the
+  // tile DMA inside the MFMA chain, at different points for the two, lets one wave's VMEM issue sit
+  // under the other's matrix work instead of both stalling the pipe right after the barrier.
+  // The chain itself is straight-line code: two copies of the tile body (lower / upper wave group),
+  // and the DMA of tile t+2 is unconditional — past the end of the range it re-fetches tile 0 into a
+  // stage nobody reads again — so no branch and no per-tile bookkeeping sits between the MFMAs.
+  const bool upper = wave >= 4;
+  constexpr int GRP = KS / PPW;                      // MFMAs between two DMA pieces
+  const char* tsrc = zc0 + 2 * (int64_t)TILEB;       // source of tile t+2
+  const char* bsrc = cb0 + 2 * B_CT * 4;
+  const uint32_t id_base = (uint32_t)(t_begin * B_CT);
 
-  int stage = 0;
-  for (int64_t t = 0; t < T; ++t) {
-    // my pieces of tile t have landed once at most the pieces of tile t+1 are outstanding
-    {
-      const bool next = (t + 1 < T);
-      const int extra = (next && wave == bias_wave(t + 1)) ? 1 : 0;
-      const int allow = next ? (((PIECES >= B_WAVES) || (wave < PIECES)) ? PPW : 0) + extra : 0;
-      // vmcnt(N) alone: expcnt = 7 and lgkmcnt = 15 mean "no wait" (gfx9 encoding)
-      if (allow == 0) __builtin_amdgcn_s_waitcnt(0x0F70);
-      else if (allow == 1) __builtin_amdgcn_s_waitcnt(0x0F71);
-      else if (allow == 2) __builtin_amdgcn_s_waitcnt(0x0F72);
-      else if (allow == 3) __builtin_amdgcn_s_waitcnt(0x0F73);
-      else if (allow == 4) __builtin_amdgcn_s_waitcnt(0x0F74);
-      else __builtin_amdgcn_s_waitcnt(0x0F75);
-    }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // tile t visible to all; everyone is done with tile t-1
-    asm volatile("" ::: "memory");
-    if (t + 2 < T) {
-      int s2 = stage + 2;
-      if (s2 >= B_STAGES) s2 -= B_STAGES;
-      issue_tile(t + 2, s2);
-      if (wave == bias_wave(t + 2)) issue_bias(t + 2, s2);
-    }
-
-    const char* tb = tiles + stage * TILEB;
-    const float* cbt = cbs + stage * 64;
+  auto tile_body = [&](auto up_tag, const char* tb, const float* cbt, const char* src, int s2) -> f32x16 {
+    constexpr bool UP = decltype(up_tag)::value;
     f32x16 acc;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -311,15 +299,84 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, af), __builtin_bit_cast(f16x8_t, qf[s]), acc, 0, 0, 0);
       else
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, qf[s]), acc, 0, 0, 0);
+      // one DMA piece of tile t+2 per group of GRP MFMAs: lower waves at the end of the group,
+      // upper waves in its middle
+      constexpr int at = UP ? ((GRP >= 2) ? GRP / 2 - 1 : 0) : GRP - 1;
+      if ((s % GRP) == at) issue_piece(src, s2, s / GRP);
     }
+    return acc;
+  };
 
+  // The filter of tile t-1 runs AFTER barrier t, ahead of this wave's own MFMA chain: a wave that
+  // falls into the (rare) list code then delays only itself while its SIMD partner issues MFMAs;
+  // placed before the barrier it would hold all eight waves, and their matrix pipes, at the barrier.
+  auto filter = [&](const f32x16& acc, int tt) {
     const float mx = max16(acc);
-    if (__any(mx >= list.thr))
-      list.template offer_tile<false>(acc, (uint32_t)((t_begin + t) * B_CT), half, a.kk, margin);
+    if (!(a.debug & 1) && __any(mx >= list.thr)) {
+      const uint32_t id0 = id_base + (uint32_t)tt * B_CT;
+      // robust (never dropping) path while thresholds are still forming: first 32 tiles of the range
+      const bool cold = (tt < 32) || __any(list.thr == -kFltMax);
+      if (a.debug & 8) {
+        const bool willc = __any(list.cnt >= B_CAP - 1);
+        int nh = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nh += (acc[r] >= list.thr) ? 1 : 0;
+        const int lanes_hit = __popcll(__ballot(nh > 0));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nh += __shfl_xor(nh, o);
+        if (lane == 0) {
+          atomicAdd(a.dbg + 0, 1ull);                       // slow-path entries
+          atomicAdd(a.dbg + 1, cold ? 1ull : 0ull);         // ... of which cold
+          atomicAdd(a.dbg + 2, (unsigned long long)nh);     // hits (values >= thr)
+          atomicAdd(a.dbg + 3, (!cold && willc) ? 1ull : 0ull);   // warm compactions
+          atomicAdd(a.dbg + 4, (unsigned long long)lanes_hit);
+        }
+      }
+      if (cold) list.template offer_tile<false>(acc, id0, half, a.kk, margin);   // cold start
+      else list.offer_tile_warm(acc, id0, half, a.kk, margin);
+    }
+    if ((a.debug & 8) && lane == 0) atomicAdd(a.dbg + 5, 1ull);   // tiles
+  };
+
+  int stage = 0;
+  f32x16 acc_prev;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_prev[r] = kNegInf;      // "tile -1": nothing can hit
+  for (int t = 0; t < Ti; ++t) {
+    // my pieces of tile t have landed once at most the pieces of tile t+1 are outstanding
+    {
+      const int allow = PPW + ((wave == ((t + 1) & 7)) ? 1 : 0);
+      // vmcnt(N) alone: expcnt = 7 and lgkmcnt = 15 mean "no wait" (gfx9 encoding)
+      if (allow == 1) __builtin_amdgcn_s_waitcnt(0x0F71);
+      else if (allow == 2) __builtin_amdgcn_s_waitcnt(0x0F72);
+      else if (allow == 3) __builtin_amdgcn_s_waitcnt(0x0F73);
+      else if (allow == 4) __builtin_amdgcn_s_waitcnt(0x0F74);
+      else __builtin_amdgcn_s_waitcnt(0x0F75);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // tile t visible to all; everyone is done READING tile t-1
+    asm volatile("" ::: "memory");
+
+    filter(acc_prev, t - 1);
+
+    const bool more = (t + 2 < Ti);
+    int s2 = stage + 2;
+    if (s2 >= B_STAGES) s2 -= B_STAGES;
+    const char* src = more ? tsrc : zc0;
+    const char* tb = tiles + stage * TILEB;
+    const float* cbt = cbs + stage * 64;
+
+    if (upper) acc_prev = tile_body(std::true_type{}, tb, cbt, src, s2);
+    else acc_prev = tile_body(std::false_type{}, tb, cbt, src, s2);
+    if (wave == ((t + 2) & 7)) issue_bias(more ? bsrc : cb0, s2);
+    tsrc += TILEB;
+    bsrc += B_CT * 4;
 
     ++stage;
     if (stage == B_STAGES) stage = 0;
   }
+  if (Ti > 0) filter(acc_prev, Ti - 1);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // the two dummy tiles still in flight
 
   list.template compact<false>(a.kk, margin);
   list.finish();
@@ -388,6 +445,17 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
   a.tiles_per_split = (a.tiles_total + col_splits - 1) / col_splits;
   a.row_blocks = (n_rows + B_QT - 1) / B_QT;
   a.col_splits = col_splits; a.kk = kk; a.metric = metric; a.d = (int)d;
+  {
+    const char* dbg = getenv("MMF_SCAN_DEBUG");
+    a.debug = dbg ? atoi(dbg) : 0;
+    a.dbg = nullptr;
+    if (a.debug & 8) {
+      static unsigned long long* dbuf = nullptr;
+      if (!dbuf) MMF_HIP(hipMalloc(&dbuf, 64));
+      MMF_HIP(hipMemsetAsync(dbuf, 0, 64, s));
+      a.dbg = dbuf;
+    }
+  }
   a.cand_cnt = L.cnt; a.cand_ids = L.ids; a.overflow = L.overflow;
   int64_t blocks = a.row_blocks * col_splits;
   int64_t grid;
@@ -398,13 +466,21 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
     grid = blocks;                                        // col_splits multiple of 8: exact
   }
   if (grid_out) *grid_out = (int)grid;
+  int rc = MMF_E_INTERNAL;
   switch (dp) {
-    case 128: return launch_b16_t<8>(a, f16, grid, s);
-    case 256: return launch_b16_t<16>(a, f16, grid, s);
-    case 512: return launch_b16_t<32>(a, f16, grid, s);
+    case 128: rc = launch_b16_t<8>(a, f16, grid, s); break;
+    case 256: rc = launch_b16_t<16>(a, f16, grid, s); break;
+    case 512: rc = launch_b16_t<32>(a, f16, grid, s); break;
+    default: set_error("scan_b16: unsupported padded dim %d", dp);
   }
-  set_error("scan_b16: unsupported padded dim %d", dp);
-  return MMF_E_INTERNAL;
+  if (rc == MMF_OK && (a.debug & 8)) {
+    unsigned long long h[8];
+    MMF_HIP(hipMemcpyAsync(h, a.dbg, 64, hipMemcpyDeviceToHost, s));
+    MMF_HIP(hipStreamSynchronize(s));
+    fprintf(stderr, "[mmf scan dbg] wave-tiles=%llu slow-entries=%llu (cold %llu) hits=%llu warm-compactions=%llu lanes-with-hit=%llu\n",
+            h[5], h[0], h[1], h[2], h[3], h[4]);
+  }
+  return rc;
 }
 
 }  // namespace mmf

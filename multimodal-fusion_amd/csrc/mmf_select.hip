@@ -34,7 +34,21 @@ __device__ __forceinline__ float chain_rows(const void* X, int64_t xr, const voi
     const f32x4* xp = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(X) + xr * d);
     const f32x4* yp = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(Y) + yr * d);
     const int64_t d4 = d >> 2;
-    for (int64_t q = 0; q < d4; ++q) {
+    int64_t q = 0;
+    // the chain is serial in k, the loads are not: fetch 8 x 16 B of each row ahead of 32 fmafs
+    for (; q + 8 <= d4; q += 8) {
+      f32x4 xv[8], yv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { xv[u] = xp[q + u]; yv[u] = yp[q + u]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc = __builtin_fmaf(xv[u][0], yv[u][0], acc);
+        acc = __builtin_fmaf(xv[u][1], yv[u][1], acc);
+        acc = __builtin_fmaf(xv[u][2], yv[u][2], acc);
+        acc = __builtin_fmaf(xv[u][3], yv[u][3], acc);
+      }
+    }
+    for (; q < d4; ++q) {
       const f32x4 xv = xp[q], yv = yp[q];
       acc = __builtin_fmaf(xv[0], yv[0], acc);
       acc = __builtin_fmaf(xv[1], yv[1], acc);
