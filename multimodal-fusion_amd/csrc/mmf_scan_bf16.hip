@@ -292,17 +292,29 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
       const f32x4 b4 = *reinterpret_cast<const f32x4*>(cbt + 8 * g + 4 * half);
       acc[4 * g + 0] = b4[0]; acc[4 * g + 1] = b4[1]; acc[4 * g + 2] = b4[2]; acc[4 * g + 3] = b4[3];
     }
+    // A fragments are read PD k-steps ahead of the MFMA that consumes them (explicit register
+    // ring): the chain never waits on an LDS read it has just issued.
+    constexpr int PD = 4;
+    u32x4 af[PD];
+#pragma unroll
+    for (int s = 0; s < PD; ++s) af[s] = *reinterpret_cast<const u32x4*>(tb + lo[s & 7] + (s >> 3) * 256);
+    __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);   // the PD leading reads first
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const u32x4 af = *reinterpret_cast<const u32x4*>(tb + lo[s & 7] + (s >> 3) * 256);
+      const u32x4 cur = af[s % PD];
+      if (s + PD < KS) af[s % PD] = *reinterpret_cast<const u32x4*>(tb + lo[(s + PD) & 7] + ((s + PD) >> 3) * 256);
       if constexpr (F16)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, af), __builtin_bit_cast(f16x8_t, qf[s]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, cur), __builtin_bit_cast(f16x8_t, qf[s]), acc, 0, 0, 0);
       else
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, qf[s]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, cur), __builtin_bit_cast(bf16x8_t, qf[s]), acc, 0, 0, 0);
       // one DMA piece of tile t+2 per group of GRP MFMAs: lower waves at the end of the group,
       // upper waves in its middle
       constexpr int at = UP ? ((GRP >= 2) ? GRP / 2 - 1 : 0) : GRP - 1;
       if ((s % GRP) == at) issue_piece(src, s2, s / GRP);
+      // pin the interleave: one LDS read (for step s+PD), then one MFMA (step s); hipcc otherwise
+      // falls back to read -> lgkmcnt(0) -> use pairs to save registers
+      if (s + PD < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
     return acc;
   };
