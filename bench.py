@@ -138,6 +138,12 @@ def main() -> None:
         flops_per_launch = 2.0 * (hi - lo) * n * d                    # 2*d flop per pair
         achieved = flops_per_launch / (scan_avg_ms * 1e-3) / 1e12 if scan_avg_ms > 0 else 0.0
         peak = PEAK_TFLOPS.get(prec, 157.3)
+        traffic = None     # HBM-side bytes per scan launch, measured offline with rocprofv3 --pmc (profiles/README.md)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            traffic = tj.get(f"N={n},d={d},gpus={world},prec={prec}", {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
         line = {
             "metric": "similarity-pairs/sec (NxN cosine+top-k)", "value": pairs / (elapsed / args.steps),
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -150,7 +156,7 @@ def main() -> None:
                        "scan_grid": stats["scan_grid"], "fallback_rows": stats["fallback_rows"],
                        "candidates_per_row": stats["candidates"] / max(1, hi - lo)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
+                         "frac": achieved / peak, "traffic": traffic,
                          "kernel": SCAN_NAME[prec], "kernel_ms": scan_avg_ms,
                          "prep_ms": stats["prep_ms"], "rerank_ms": stats["rerank_ms"], "fallback_ms": stats["fallback_ms"]},
         }
