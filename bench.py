@@ -79,6 +79,8 @@ def main() -> None:
     ap.add_argument("--metric", default="cosine")
     ap.add_argument("--precision", default="auto", choices=["auto", "exact", "fast", "fast_bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the multi-rank path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
     import torch
@@ -93,11 +95,15 @@ def main() -> None:
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     n, d, k = args.n, args.d, args.k
     lo, hi = dmod.shard_bounds(n, world, rank)

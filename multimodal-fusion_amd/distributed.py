@@ -31,6 +31,10 @@ def all_gather_rows(x_local: torch.Tensor, n_total: int, group=None) -> torch.Te
     d = x_local.shape[1]
     sizes = [shard_bounds(n_total, world, r) for r in range(world)]
     heights = [hi - lo for lo, hi in sizes]
+    if x_local.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal path (gloo has no device collectives): stage through the host.  The production
+        # backend is "nccl" (= RCCL over xGMI on ROCm) and never takes this branch.
+        return all_gather_rows(x_local.cpu(), n_total, group).to(x_local.device)
     full = torch.empty((n_total, d), dtype=x_local.dtype, device=x_local.device)
     if len(set(heights)) == 1:
         dist.all_gather_into_tensor(full, x_local.contiguous(), group=group)
