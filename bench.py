@@ -73,9 +73,9 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=262144)
-    ap.add_argument("--d", type=int, default=512)
-    ap.add_argument("--k", type=int, default=5)
+    ap.add_argument("--rows", dest="n", type=int, default=262144)
+    ap.add_argument("--dim", dest="d", type=int, default=512)
+    ap.add_argument("--topk", dest="k", type=int, default=5)
     ap.add_argument("--metric", default="cosine")
     ap.add_argument("--precision", default="auto", choices=["auto", "exact", "fast", "fast_bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
