@@ -191,7 +191,18 @@ int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d
     const bool f16 = (precision == MMF_PREC_FAST);   // operand type of the scan, not of the input
     const int bcap = scan_bf16_cap();
     const bool same = (Y == X) && (m == n);
-    const int64_t n_pad = (n + 255) / 256 * 256, m_pad = (m + 255) / 256 * 256;
+    // X a row-slice of Y (the row-sharded multi-GPU case passes full[lo:hi] and full): every query-side
+    // buffer is then a view into the candidate-side one and only Y is prepared.
+    const size_t row_bytes = (size_t)d * dtype_size(in_dtype);
+    int64_t slice0 = -1;
+    if (!same) {
+      const char* xb = static_cast<const char*>(X);
+      const char* yb = static_cast<const char*>(Y);
+      if (xb >= yb && xb + (size_t)n * row_bytes <= yb + (size_t)m * row_bytes && ((size_t)(xb - yb) % row_bytes) == 0)
+        slice0 = (int64_t)((size_t)(xb - yb) / row_bytes);
+    }
+    const bool shared = same || slice0 >= 0;
+    const int64_t n_pad = (n + 255) / 256 * 256, m_pad = (m + 255) / 256 * 256 + (slice0 >= 0 ? 256 : 0);
     const int64_t row_blocks = n_pad / 256, col_tiles = m_pad / 32;
     int splits = 1;
     if (forced_splits > 0) { while (splits < forced_splits) splits <<= 1; }
@@ -210,16 +221,23 @@ int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d
                   ws_bytes((size_t)FB * fb_lists * cap, 4) + 2 * ws_bytes(FB, 4) + ws_bytes(4, 4);
     Workspace ws;
     MMF_TRY(get_workspace(device_id, s, need, &ws));
-    float* rx = ws.take<float>(n);
-    float* cy = same ? rx : ws.take<float>(m);
-    uint16_t* ZQ = ws.take<uint16_t>((size_t)n_pad * dp);
-    uint16_t* ZC = same ? ZQ : ws.take<uint16_t>((size_t)m_pad * dp);
-    float* q_zn = ws.take<float>(n_pad); float* q_rn = ws.take<float>(n_pad);
-    float* q_un = ws.take<float>(n_pad); float* q_cb = ws.take<float>(n_pad);
-    float *c_zn = q_zn, *c_rn = q_rn, *c_un = q_un, *c_cb = q_cb;
-    if (!same) { c_zn = ws.take<float>(m_pad); c_rn = ws.take<float>(m_pad); c_un = ws.take<float>(m_pad); c_cb = ws.take<float>(m_pad); }
-    uint32_t* max_q = ws.take<uint32_t>(4);
-    uint32_t* max_c = same ? max_q : ws.take<uint32_t>(4);
+    float *rx, *cy, *q_zn, *q_rn, *q_un, *q_cb, *c_zn, *c_rn, *c_un, *c_cb;
+    uint16_t *ZQ, *ZC;
+    uint32_t *max_q, *max_c;
+    if (shared) {
+      const int64_t r0 = same ? 0 : slice0;
+      cy = ws.take<float>(m); rx = cy + r0;
+      ZC = ws.take<uint16_t>((size_t)m_pad * dp); ZQ = ZC + (size_t)r0 * dp;
+      c_zn = ws.take<float>(m_pad); c_rn = ws.take<float>(m_pad); c_un = ws.take<float>(m_pad); c_cb = ws.take<float>(m_pad);
+      q_zn = c_zn + r0; q_rn = c_rn + r0; q_un = c_un + r0; q_cb = c_cb + r0;
+      max_c = ws.take<uint32_t>(4); max_q = max_c;
+    } else {
+      rx = ws.take<float>(n); cy = ws.take<float>(m);
+      ZQ = ws.take<uint16_t>((size_t)n_pad * dp); ZC = ws.take<uint16_t>((size_t)m_pad * dp);
+      q_zn = ws.take<float>(n_pad); q_rn = ws.take<float>(n_pad); q_un = ws.take<float>(n_pad); q_cb = ws.take<float>(n_pad);
+      c_zn = ws.take<float>(m_pad); c_rn = ws.take<float>(m_pad); c_un = ws.take<float>(m_pad); c_cb = ws.take<float>(m_pad);
+      max_q = ws.take<uint32_t>(4); max_c = ws.take<uint32_t>(4);
+    }
     uint32_t* max_n = ws.take<uint32_t>(4);   // largest squared row norm over X and Y -> common scale
     CandLists L;
     L.cnt = ws.take<uint32_t>((size_t)n * lists);
@@ -240,21 +258,21 @@ int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d
     MMF_HIP(hipMemsetAsync(L.overflow, 0, (size_t)n * 4, s));
     MMF_HIP(hipMemsetAsync(fail_count, 0, 16, s));
     MMF_HIP(hipMemsetAsync(cand_total, 0, 1024, s));
-    MMF_HIP(hipMemsetAsync(max_q, 0, 16, s));
+    MMF_HIP(hipMemsetAsync(max_c, 0, 16, s));
     MMF_HIP(hipMemsetAsync(max_n, 0, 16, s));
-    if (!same) MMF_HIP(hipMemsetAsync(max_c, 0, 16, s));
+    if (!shared) MMF_HIP(hipMemsetAsync(max_q, 0, 16, s));
 
     EventTimer t_prep, t_scan, t_sel, t_fb;
     MMF_TRY(t_prep.start(profile, s));
-    MMF_TRY(launch_row_scalars(X, n, d, in_dtype, metric, rx, max_n, s));
-    if (!same) MMF_TRY(launch_row_scalars(Y, m, d, in_dtype, metric, cy, max_n, s));
-    MMF_TRY(launch_prep_half(X, n, d, in_dtype, metric, rx, max_n, ZQ, n_pad, dp, f16 ? 1 : 0, q_zn, q_rn, q_un, q_cb, max_q, s));
-    if (!same) MMF_TRY(launch_prep_half(Y, m, d, in_dtype, metric, cy, max_n, ZC, m_pad, dp, f16 ? 1 : 0, c_zn, c_rn, c_un, c_cb, max_c, s));
+    MMF_TRY(launch_row_scalars(Y, m, d, in_dtype, metric, cy, max_n, s));
+    if (!shared) MMF_TRY(launch_row_scalars(X, n, d, in_dtype, metric, rx, max_n, s));
+    MMF_TRY(launch_prep_half(Y, m, d, in_dtype, metric, cy, max_n, ZC, m_pad, dp, f16 ? 1 : 0, c_zn, c_rn, c_un, c_cb, max_c, s));
+    if (!shared) MMF_TRY(launch_prep_half(X, n, d, in_dtype, metric, rx, max_n, ZQ, n_pad, dp, f16 ? 1 : 0, q_zn, q_rn, q_un, q_cb, max_q, s));
     MMF_TRY(t_prep.stop(s));
 
     int grid = 0;
     MMF_TRY(t_scan.start(profile, s));
-    MMF_TRY(launch_scan_b16(ZQ, ZC, c_cb, q_zn, q_rn, q_un, max_c, n, m, m_pad, dp, d, f16, metric, kk, splits, L, s, &grid));
+    MMF_TRY(launch_scan_b16(ZQ, ZC, c_cb, q_zn, q_rn, q_un, max_c, n, m, (m + 255) / 256 * 256, dp, d, f16, metric, kk, splits, L, s, &grid));
     MMF_TRY(t_scan.stop(s));
 
     SelectProblem q{};

@@ -70,16 +70,19 @@ def sharded_simtopk(x_local: torch.Tensor, n_total: int, *, metric="cosine", lam
     if op is None:
         from . import ops
         op = ops.simtopk
+    # hand the op the local rows as a VIEW of the gathered matrix: libmmf_hg.so recognises a row
+    # slice of Y and prepares the operands once
+    x_rows = full[lo:hi] if world > 1 else x_local
     kw = dict(metric=metric, lam=lam, k=k, exclude_self=exclude_self, row_offset=lo, col_offset=0)
     stats = None
     if op.__module__.endswith("ops"):
-        out = op(x_local, full, precision=precision, return_stats=return_stats, profile=return_stats, **kw)
+        out = op(x_rows, full, precision=precision, return_stats=return_stats, profile=return_stats, **kw)
         if return_stats:
             idx, val, stats = out
         else:
             idx, val = out
     else:
-        idx, val = op(x_local, full, **kw)
+        idx, val = op(x_rows, full, **kw)
     if gather_output and world > 1:
         idx = all_gather_rows(idx, n_total, group)
         val = all_gather_rows(val, n_total, group)
