@@ -101,6 +101,8 @@ typedef struct mmf_simtopk_opts {
   int      profile;        /* 1: bracket the scan kernel with HIP events on hip_stream           */
   int      col_splits;     /* 0 = auto; >0 forces the number of column ranges per row block      */
   int      reserved0;
+  void*    select_wait_event; /* optional hipEvent_t: the stream waits for it after the 16-bit scan and
+                                 before anything reads the f32 rows of X / Y (overlapped all-gather)    */
 } mmf_simtopk_opts;
 
 typedef struct mmf_simtopk_stats {
@@ -125,6 +127,49 @@ int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d
                    const mmf_simtopk_opts* opts /* NULL = defaults */,
                    mmf_simtopk_stats* stats /* host, may be NULL */,
                    int device_id, void* hip_stream);
+
+/*
+ * Phase API of the fast path, for the row-sharded multi-GPU driver: every rank prepares
+ * the 16-bit operands of ITS rows once, ranks exchange them (half the bytes of the f32 rows), and the
+ * scan runs on prepared operands while the f32 rows — needed only by the exact re-rank — are still
+ * arriving.  Results are bit-identical to mmf_simtopk.  No reference counterpart.
+ *
+ *   mmf_padded_dim(d)      padded feature dim DP of the 16-bit operands (0: d unsupported, use mmf_simtopk)
+ *   mmf_row_scalars        scal[i] = canonical n_i (clamped norm for MMF_COSINE); *max_sq_norm is raised
+ *                          atomically to max n_i (caller zeroes it; may be NULL)
+ *   mmf_prep_rows          Z[n_pad, DP] = round_16(u * 2^e) with e from *max_sq_norm (the GLOBAL maximum:
+ *                          all-reduce it first; ignored for MMF_COSINE), rows n..n_pad zero with cb = -inf;
+ *                          zn / rn / un / cb [n_pad]; maxima[4] raised atomically (caller zeroes; all-reduce MAX)
+ *   mmf_simtopk_prepared   X:[n,d], Y:[m,d] are the ORIGINAL rows (read by the re-rank only);
+ *                          q / c are the prepared query / candidate sides.  c->Z and c->cb hold m_pad rows
+ *                          (multiple of 256, >= m; padding rows zero / -inf); q->Z, q->zn, q->rn, q->un must be
+ *                          readable for n rounded up to 256 rows (e.g. views into the candidate side
+ *                          allocated with 256 rows of slack).  maxima[4] = global maxima of the candidate side.
+ */
+typedef struct mmf_prepared_side {
+  const void*  Z;
+  const float* scal;
+  const float* zn;
+  const float* rn;
+  const float* un;
+  const float* cb;
+} mmf_prepared_side;
+
+int64_t mmf_padded_dim(int64_t d);
+int mmf_row_scalars(const void* X, int64_t n, int64_t d, int in_dtype, int metric, float* scal,
+                    float* max_sq_norm, int device_id, void* hip_stream);
+int mmf_prep_rows(const void* X, int64_t n, int64_t d, int in_dtype, int metric, int operand,
+                  const float* scal, const float* max_sq_norm, void* Z, int64_t n_pad,
+                  float* zn, float* rn, float* un, float* cb, float* maxima,
+                  int device_id, void* hip_stream);
+int mmf_simtopk_prepared(const void* X, int64_t n, const void* Y, int64_t m, int64_t d,
+                         int in_dtype, int metric, float lambda, int k, int exclude_self,
+                         int64_t row_offset, int64_t col_offset,
+                         const mmf_prepared_side* q, const mmf_prepared_side* c, int64_t m_pad,
+                         const float* maxima, int operand,
+                         int64_t* out_idx, float* out_val,
+                         const mmf_simtopk_opts* opts, mmf_simtopk_stats* stats,
+                         int device_id, void* hip_stream);
 
 /*
  * Merge two sorted [n,k] partial results into one (column-panel streaming, cross-shard merges).

@@ -17,7 +17,12 @@ PRECISIONS = {"auto": 0, "exact": 1, "fast": 2, "fast_bf16": 3}
 
 class SimtopkOpts(ctypes.Structure):
     _fields_ = [("precision", ctypes.c_int), ("profile", ctypes.c_int), ("col_splits", ctypes.c_int),
-                ("reserved0", ctypes.c_int)]
+                ("reserved0", ctypes.c_int), ("select_wait_event", ctypes.c_void_p)]
+
+
+class PreparedSide(ctypes.Structure):
+    _fields_ = [("Z", ctypes.c_void_p), ("scal", ctypes.c_void_p), ("zn", ctypes.c_void_p), ("rn", ctypes.c_void_p),
+                ("un", ctypes.c_void_p), ("cb", ctypes.c_void_p)]
 
 
 class SimtopkStats(ctypes.Structure):
@@ -32,7 +37,8 @@ class SimtopkStats(ctypes.Structure):
 
 _lib = None
 
-EXPORTS = ["mmf_version", "mmf_last_error", "mmf_simtopk", "mmf_simtopk_ex", "mmf_topk_merge", "mmf_edge_cosine",
+EXPORTS = ["mmf_version", "mmf_last_error", "mmf_simtopk", "mmf_simtopk_ex", "mmf_row_scalars", "mmf_prep_rows",
+           "mmf_simtopk_prepared", "mmf_padded_dim", "mmf_topk_merge", "mmf_edge_cosine",
            "mmf_sim_dense", "mmf_sim_dense_combined", "mmf_offdiag_lower_median", "mmf_threshold_edges",
            "mmf_release_workspaces"]
 
@@ -52,6 +58,12 @@ def lib() -> ctypes.CDLL:
     L.mmf_simtopk.argtypes = [vp, i64, vp, i64, i64, ci, ci, f32, ci, ci, i64, i64, vp, vp, ci, vp]
     L.mmf_simtopk_ex.argtypes = [vp, i64, vp, i64, i64, ci, ci, f32, ci, ci, i64, i64, vp, vp,
                                  ctypes.POINTER(SimtopkOpts), ctypes.POINTER(SimtopkStats), ci, vp]
+    L.mmf_padded_dim.argtypes = [i64]
+    L.mmf_row_scalars.argtypes = [vp, i64, i64, ci, ci, vp, vp, ci, vp]
+    L.mmf_prep_rows.argtypes = [vp, i64, i64, ci, ci, ci, vp, vp, vp, i64, vp, vp, vp, vp, vp, ci, vp]
+    L.mmf_simtopk_prepared.argtypes = [vp, i64, vp, i64, i64, ci, ci, f32, ci, ci, i64, i64,
+                                       ctypes.POINTER(PreparedSide), ctypes.POINTER(PreparedSide), i64, vp, ci, vp, vp,
+                                       ctypes.POINTER(SimtopkOpts), ctypes.POINTER(SimtopkStats), ci, vp]
     L.mmf_topk_merge.argtypes = [vp, vp, vp, vp, i64, ci, vp, vp, ci, vp]
     L.mmf_edge_cosine.argtypes = [vp, i64, i64, ci, vp, i64, vp, ci, vp]
     L.mmf_sim_dense.argtypes = [vp, i64, vp, i64, i64, ci, ci, f32, vp, ci, vp]
@@ -60,8 +72,9 @@ def lib() -> ctypes.CDLL:
     L.mmf_threshold_edges.argtypes = [vp, i64, f32, vp, vp, i64, vp, ci, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name not in ("mmf_last_error",):
+        if name not in ("mmf_last_error", "mmf_padded_dim"):
             fn.restype = ci
+    L.mmf_padded_dim.restype = i64
     L.mmf_last_error.restype = ctypes.c_char_p
     if L.mmf_version() != 1:
         raise RuntimeError(f"libmmf_hg.so ABI version {L.mmf_version()} != 1")

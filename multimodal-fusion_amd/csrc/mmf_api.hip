@@ -116,6 +116,129 @@ static int pick_splits(int64_t row_blocks, int64_t col_tiles, int lists_cap, int
   return (int)s;
 }
 
+// Everything of the fast path after the 16-bit operands exist: candidate lists, scan, (optional event
+// wait), exact re-rank, exact rescan of flagged rows, stats.  Shared by mmf_simtopk_ex and
+// mmf_simtopk_prepared.
+struct FastOperands {
+  const uint16_t* ZQ; const uint16_t* ZC;
+  const float* rx; const float* cy;
+  const float* q_zn; const float* q_rn; const float* q_un;
+  const float* c_cb; const uint32_t* max_c;
+  int64_t m_pad_tiles;   // candidate rows covered by tiles (multiple of 256)
+  int dp; bool f16;
+};
+
+struct FastTail {
+  int64_t n, m; int kk, cap, bcap, splits, lists, fb_splits, fb_lists; int64_t FB;
+  CandLists L, FL;
+  int32_t *fail_rows = nullptr, *fb_fail_rows = nullptr;
+  uint32_t *fail_count = nullptr, *cand_total = nullptr, *fb_fail_count = nullptr;
+
+  FastTail(int64_t n_, int64_t m_, int kk_, int cap_, int forced_splits) : n(n_), m(m_), kk(kk_), cap(cap_) {
+    bcap = scan_bf16_cap();
+    const int64_t row_blocks = (n + 255) / 256, col_tiles = ((m + 255) / 256 * 256) / 32;
+    splits = 1;
+    if (forced_splits > 0) { while (splits < forced_splits) splits <<= 1; }
+    else { while (row_blocks * splits < 256 && splits < 32) splits <<= 1; }
+    while (splits > 1 && (splits > col_tiles || 2 * splits * bcap > 1024)) splits >>= 1;
+    lists = 2 * splits;
+    FB = n < 4096 ? n : 4096;   // exact rescans are done in batches of at most FB rows
+    fb_splits = pick_splits((FB + 127) / 128, (m + 127) / 128, 0, cap, 0);
+    fb_lists = 2 * fb_splits;
+  }
+  size_t bytes() const {
+    return ws_bytes((size_t)n * lists, 4) + ws_bytes((size_t)n * lists * bcap, 4) + 2 * ws_bytes(n, 4) + ws_bytes(4, 4) +
+           ws_bytes(256, 4) + ws_bytes((size_t)FB * fb_lists, 4) + ws_bytes((size_t)FB * fb_lists * cap, 4) +
+           2 * ws_bytes(FB, 4) + ws_bytes(4, 4);
+  }
+  void carve(Workspace& ws) {
+    L.cnt = ws.take<uint32_t>((size_t)n * lists);
+    L.ids = ws.take<uint32_t>((size_t)n * lists * bcap);
+    L.overflow = ws.take<uint32_t>(n);
+    L.lists = lists; L.cap = bcap;
+    fail_rows = ws.take<int32_t>(n);
+    fail_count = ws.take<uint32_t>(4);
+    cand_total = ws.take<uint32_t>(256);
+    FL.cnt = ws.take<uint32_t>((size_t)FB * fb_lists);
+    FL.ids = ws.take<uint32_t>((size_t)FB * fb_lists * cap);
+    FL.overflow = ws.take<uint32_t>(FB);
+    FL.lists = fb_lists; FL.cap = cap;
+    fb_fail_rows = ws.take<int32_t>(FB);
+    fb_fail_count = ws.take<uint32_t>(4);
+  }
+  int run(const void* X, int64_t n_, const void* Y, int64_t m_, int64_t d, int in_dtype, int metric, float lambda, int k,
+          int exclude_self, int64_t row_offset, int64_t col_offset, const FastOperands& fo, int64_t* out_idx,
+          float* out_val, bool profile, void* select_wait_event, mmf_simtopk_stats* stats, int precision, hipStream_t s) {
+    MMF_HIP(hipMemsetAsync(L.overflow, 0, (size_t)n * 4, s));
+    MMF_HIP(hipMemsetAsync(fail_count, 0, 16, s));
+    MMF_HIP(hipMemsetAsync(cand_total, 0, 1024, s));
+    EventTimer t_scan, t_sel, t_fb;
+    int grid = 0;
+    MMF_TRY(t_scan.start(profile, s));
+    MMF_TRY(launch_scan_b16(fo.ZQ, fo.ZC, fo.c_cb, fo.q_zn, fo.q_rn, fo.q_un, fo.max_c, n, m, fo.m_pad_tiles, fo.dp, d, fo.f16,
+                            metric, kk, splits, L, s, &grid));
+    MMF_TRY(t_scan.stop(s));
+    // the f32 rows are first touched here: a caller that is still receiving them (overlapped
+    // all-gather) hands in the event that marks their arrival
+    if (select_wait_event) MMF_HIP(hipStreamWaitEvent(s, static_cast<hipEvent_t>(select_wait_event), 0));
+
+    SelectProblem q{};
+    q.X = X; q.n = n; q.Y = Y; q.m = m; q.d = d; q.dtype = in_dtype; q.metric = metric; q.lambda = lambda;
+    q.k = k; q.exclude_self = exclude_self; q.row_offset = row_offset; q.col_offset = col_offset;
+    q.rx = fo.rx; q.cy = fo.cy; q.row_ids = nullptr; q.n_rows = n; q.out_idx = out_idx; q.out_val = out_val;
+    q.fail_rows = fail_rows; q.fail_count = fail_count; q.cand_total = stats ? cand_total : nullptr;
+    MMF_TRY(t_sel.start(profile, s));
+    MMF_TRY(launch_select(q, L, s));
+    MMF_TRY(t_sel.stop(s));
+
+    uint32_t h_fail4[4] = {0, 0, 0, 0};
+    MMF_HIP(hipMemcpyAsync(h_fail4, fail_count, 16, hipMemcpyDeviceToHost, s));
+    std::vector<uint32_t> h_tot(stats ? 256 : 0);
+    if (stats) MMF_HIP(hipMemcpyAsync(h_tot.data(), cand_total, 1024, hipMemcpyDeviceToHost, s));
+    MMF_HIP(hipStreamSynchronize(s));
+    const uint32_t h_fail = h_fail4[0];
+
+    MMF_TRY(t_fb.start(profile && h_fail > 0, s));
+    for (int64_t off = 0; off < (int64_t)h_fail; off += FB) {
+      const int64_t nb = ((int64_t)h_fail - off < FB) ? ((int64_t)h_fail - off) : FB;
+      MMF_HIP(hipMemsetAsync(FL.overflow, 0, (size_t)nb * 4, s));
+      MMF_HIP(hipMemsetAsync(fb_fail_count, 0, 16, s));
+      ScanProblem sp{};
+      sp.X = X; sp.n = n; sp.Y = Y; sp.m = m; sp.d = d; sp.dtype = in_dtype; sp.metric = metric; sp.lambda = lambda;
+      sp.kk = kk; sp.rx = fo.rx; sp.cy = fo.cy; sp.row_ids = fail_rows + off; sp.n_rows = nb; sp.col_splits = fb_splits;
+      MMF_TRY(launch_scan_f32(sp, FL, s, nullptr));
+      SelectProblem fq = q;
+      fq.row_ids = fail_rows + off; fq.n_rows = nb; fq.fail_rows = fb_fail_rows; fq.fail_count = fb_fail_count;
+      fq.cand_total = nullptr;
+      MMF_TRY(launch_select(fq, FL, s));
+      uint32_t h_fb = 0;
+      MMF_HIP(hipMemcpyAsync(&h_fb, fb_fail_count, 4, hipMemcpyDeviceToHost, s));
+      MMF_HIP(hipStreamSynchronize(s));
+      if (h_fb != 0) {
+        set_error("simtopk: %u rows failed in the exact rescan (internal invariant)", h_fb);
+        return MMF_E_INTERNAL;
+      }
+    }
+    MMF_TRY(t_fb.stop(s));
+    if (stats) {
+      stats->precision_used = precision;
+      stats->col_splits = splits;
+      stats->scan_grid = grid;
+      stats->scan_ms = t_scan.ms();
+      stats->rerank_ms = t_sel.ms();
+      stats->fallback_ms = t_fb.ms();
+      stats->fallback_rows = h_fail;
+      stats->overflow_rows = h_fail4[1];
+      stats->short_rows = h_fail4[2];
+      int64_t tot = 0;
+      for (uint32_t v : h_tot) tot += v;
+      stats->candidates = tot;
+    }
+    (void)n_; (void)m_;
+    return MMF_OK;
+  }
+};
+
 }  // namespace mmf
 
 using namespace mmf;
@@ -186,10 +309,9 @@ int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d
   if (cap == 0) { set_error("simtopk: k = %d is above the supported maximum (27 with self excluded, 28 without)", k); return MMF_E_UNSUPPORTED; }
 
   if (precision != MMF_PREC_EXACT) {
-    // ---- fast path: bf16/f16 MFMA scan -> exact re-rank -> exact rescan of overflowed rows -------
+    // ---- fast path: f16/bf16 MFMA scan -> exact re-rank -> exact rescan of overflowed rows -------
     const int dp = scan_bf16_dp(d);
     const bool f16 = (precision == MMF_PREC_FAST);   // operand type of the scan, not of the input
-    const int bcap = scan_bf16_cap();
     const bool same = (Y == X) && (m == n);
     // X a row-slice of Y (the row-sharded multi-GPU case passes full[lo:hi] and full): every query-side
     // buffer is then a view into the candidate-side one and only Y is prepared.
@@ -203,22 +325,9 @@ int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d
     }
     const bool shared = same || slice0 >= 0;
     const int64_t n_pad = (n + 255) / 256 * 256, m_pad = (m + 255) / 256 * 256 + (slice0 >= 0 ? 256 : 0);
-    const int64_t row_blocks = n_pad / 256, col_tiles = m_pad / 32;
-    int splits = 1;
-    if (forced_splits > 0) { while (splits < forced_splits) splits <<= 1; }
-    else { while (row_blocks * splits < 256 && splits < 32) splits <<= 1; }
-    while (splits > 1 && (splits > col_tiles || 2 * splits * bcap > 1024)) splits >>= 1;
-    const int lists = 2 * splits;
-    // exact rescans are done in batches of at most FB rows
-    const int64_t FB = n < 4096 ? n : 4096;
-    const int64_t fb_blocks = (FB + 127) / 128, fb_tiles = (m + 127) / 128;
-    const int fb_splits = pick_splits(fb_blocks, fb_tiles, 0, cap, 0);
-    const int fb_lists = 2 * fb_splits;
+    FastTail ft(n, m, kk, cap, forced_splits);
     size_t need = ws_bytes(n, 4) + ws_bytes(m, 4) + ws_bytes((size_t)n_pad * dp, 2) + ws_bytes((size_t)m_pad * dp, 2) +
-                  4 * ws_bytes(n_pad, 4) + 4 * ws_bytes(m_pad, 4) + 3 * ws_bytes(4, 4) +
-                  ws_bytes((size_t)n * lists, 4) + ws_bytes((size_t)n * lists * bcap, 4) + 2 * ws_bytes(n, 4) +
-                  ws_bytes(4, 4) + ws_bytes(256, 4) + ws_bytes((size_t)FB * fb_lists, 4) +
-                  ws_bytes((size_t)FB * fb_lists * cap, 4) + 2 * ws_bytes(FB, 4) + ws_bytes(4, 4);
+                  4 * ws_bytes(n_pad, 4) + 4 * ws_bytes(m_pad, 4) + 3 * ws_bytes(4, 4) + ft.bytes();
     Workspace ws;
     MMF_TRY(get_workspace(device_id, s, need, &ws));
     float *rx, *cy, *q_zn, *q_rn, *q_un, *q_cb, *c_zn, *c_rn, *c_un, *c_cb;
@@ -239,30 +348,12 @@ int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d
       max_q = ws.take<uint32_t>(4); max_c = ws.take<uint32_t>(4);
     }
     uint32_t* max_n = ws.take<uint32_t>(4);   // largest squared row norm over X and Y -> common scale
-    CandLists L;
-    L.cnt = ws.take<uint32_t>((size_t)n * lists);
-    L.ids = ws.take<uint32_t>((size_t)n * lists * bcap);
-    L.overflow = ws.take<uint32_t>(n);
-    L.lists = lists; L.cap = bcap;
-    int32_t* fail_rows = ws.take<int32_t>(n);
-    uint32_t* fail_count = ws.take<uint32_t>(4);
-    uint32_t* cand_total = ws.take<uint32_t>(256);
-    CandLists FL;
-    FL.cnt = ws.take<uint32_t>((size_t)FB * fb_lists);
-    FL.ids = ws.take<uint32_t>((size_t)FB * fb_lists * cap);
-    FL.overflow = ws.take<uint32_t>(FB);
-    FL.lists = fb_lists; FL.cap = cap;
-    int32_t* fb_fail_rows = ws.take<int32_t>(FB);
-    uint32_t* fb_fail_count = ws.take<uint32_t>(4);
-
-    MMF_HIP(hipMemsetAsync(L.overflow, 0, (size_t)n * 4, s));
-    MMF_HIP(hipMemsetAsync(fail_count, 0, 16, s));
-    MMF_HIP(hipMemsetAsync(cand_total, 0, 1024, s));
+    ft.carve(ws);
     MMF_HIP(hipMemsetAsync(max_c, 0, 16, s));
     MMF_HIP(hipMemsetAsync(max_n, 0, 16, s));
     if (!shared) MMF_HIP(hipMemsetAsync(max_q, 0, 16, s));
 
-    EventTimer t_prep, t_scan, t_sel, t_fb;
+    EventTimer t_prep;
     MMF_TRY(t_prep.start(profile, s));
     MMF_TRY(launch_row_scalars(Y, m, d, in_dtype, metric, cy, max_n, s));
     if (!shared) MMF_TRY(launch_row_scalars(X, n, d, in_dtype, metric, rx, max_n, s));
@@ -270,63 +361,10 @@ int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d
     if (!shared) MMF_TRY(launch_prep_half(X, n, d, in_dtype, metric, rx, max_n, ZQ, n_pad, dp, f16 ? 1 : 0, q_zn, q_rn, q_un, q_cb, max_q, s));
     MMF_TRY(t_prep.stop(s));
 
-    int grid = 0;
-    MMF_TRY(t_scan.start(profile, s));
-    MMF_TRY(launch_scan_b16(ZQ, ZC, c_cb, q_zn, q_rn, q_un, max_c, n, m, (m + 255) / 256 * 256, dp, d, f16, metric, kk, splits, L, s, &grid));
-    MMF_TRY(t_scan.stop(s));
-
-    SelectProblem q{};
-    q.X = X; q.n = n; q.Y = Y; q.m = m; q.d = d; q.dtype = in_dtype; q.metric = metric; q.lambda = lambda;
-    q.k = k; q.exclude_self = exclude_self; q.row_offset = row_offset; q.col_offset = col_offset;
-    q.rx = rx; q.cy = cy; q.row_ids = nullptr; q.n_rows = n; q.out_idx = out_idx; q.out_val = out_val;
-    q.fail_rows = fail_rows; q.fail_count = fail_count; q.cand_total = stats ? cand_total : nullptr;
-    MMF_TRY(t_sel.start(profile, s));
-    MMF_TRY(launch_select(q, L, s));
-    MMF_TRY(t_sel.stop(s));
-
-    uint32_t h_fail4[4] = {0, 0, 0, 0};
-    MMF_HIP(hipMemcpyAsync(h_fail4, fail_count, 16, hipMemcpyDeviceToHost, s));
-    std::vector<uint32_t> h_tot(stats ? 256 : 0);
-    if (stats) MMF_HIP(hipMemcpyAsync(h_tot.data(), cand_total, 1024, hipMemcpyDeviceToHost, s));
-    MMF_HIP(hipStreamSynchronize(s));
-    const uint32_t h_fail = h_fail4[0];
-    if (stats) { stats->overflow_rows = h_fail4[1]; stats->short_rows = h_fail4[2]; }
-
-    MMF_TRY(t_fb.start(profile && h_fail > 0, s));
-    for (int64_t off = 0; off < (int64_t)h_fail; off += FB) {
-      const int64_t nb = ((int64_t)h_fail - off < FB) ? ((int64_t)h_fail - off) : FB;
-      MMF_HIP(hipMemsetAsync(FL.overflow, 0, (size_t)nb * 4, s));
-      MMF_HIP(hipMemsetAsync(fb_fail_count, 0, 16, s));
-      ScanProblem sp{};
-      sp.X = X; sp.n = n; sp.Y = Y; sp.m = m; sp.d = d; sp.dtype = in_dtype; sp.metric = metric; sp.lambda = lambda;
-      sp.kk = kk; sp.rx = rx; sp.cy = cy; sp.row_ids = fail_rows + off; sp.n_rows = nb; sp.col_splits = fb_splits;
-      MMF_TRY(launch_scan_f32(sp, FL, s, nullptr));
-      SelectProblem fq = q;
-      fq.row_ids = fail_rows + off; fq.n_rows = nb; fq.fail_rows = fb_fail_rows; fq.fail_count = fb_fail_count;
-      fq.cand_total = nullptr;
-      MMF_TRY(launch_select(fq, FL, s));
-      uint32_t h_fb = 0;
-      MMF_HIP(hipMemcpyAsync(&h_fb, fb_fail_count, 4, hipMemcpyDeviceToHost, s));
-      MMF_HIP(hipStreamSynchronize(s));
-      if (h_fb != 0) {
-        set_error("simtopk: %u rows failed in the exact rescan (internal invariant)", h_fb);
-        return MMF_E_INTERNAL;
-      }
-    }
-    MMF_TRY(t_fb.stop(s));
-    if (stats) {
-      stats->precision_used = precision;
-      stats->col_splits = splits;
-      stats->scan_grid = grid;
-      stats->prep_ms = t_prep.ms();
-      stats->scan_ms = t_scan.ms();
-      stats->rerank_ms = t_sel.ms();
-      stats->fallback_ms = t_fb.ms();
-      stats->fallback_rows = h_fail;
-      int64_t tot = 0;
-      for (uint32_t v : h_tot) tot += v;
-      stats->candidates = tot;
-    }
+    FastOperands fo{ZQ, ZC, rx, cy, q_zn, q_rn, q_un, c_cb, max_c, (m + 255) / 256 * 256, dp, f16};
+    MMF_TRY(ft.run(X, n, Y, m, d, in_dtype, metric, lambda, k, exclude_self, row_offset, col_offset, fo, out_idx, out_val,
+                   profile, opts ? opts->select_wait_event : nullptr, stats, precision, s));
+    if (stats) stats->prep_ms = t_prep.ms();
     return MMF_OK;
   }
 
@@ -405,6 +443,75 @@ int mmf_simtopk(const void* X, int64_t n, const void* Y, int64_t m, int64_t d, i
                 int device_id, void* hip_stream) {
   return mmf_simtopk_ex(X, n, Y, m, d, in_dtype, metric, lambda, k, exclude_self, row_offset, col_offset, out_idx,
                         out_val, nullptr, nullptr, device_id, hip_stream);
+}
+
+int64_t mmf_padded_dim(int64_t d) { return (int64_t)scan_bf16_dp(d); }
+
+int mmf_row_scalars(const void* X, int64_t n, int64_t d, int in_dtype, int metric, float* scal, float* max_sq_norm,
+                    int device_id, void* hip_stream) {
+  MMF_TRY(check_common(X, n, n, d, in_dtype, device_id));
+  if (metric < MMF_DOT || metric > MMF_RBF) { set_error("row_scalars: bad metric %d", metric); return MMF_E_INVALID; }
+  if (n == 0) return MMF_OK;
+  if (!scal) { set_error("row_scalars: NULL output"); return MMF_E_INVALID; }
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  return launch_row_scalars(X, n, d, in_dtype, metric, scal, reinterpret_cast<uint32_t*>(max_sq_norm),
+                            static_cast<hipStream_t>(hip_stream));
+}
+
+int mmf_prep_rows(const void* X, int64_t n, int64_t d, int in_dtype, int metric, int operand, const float* scal,
+                  const float* max_sq_norm, void* Z, int64_t n_pad, float* zn, float* rn, float* un, float* cb,
+                  float* maxima, int device_id, void* hip_stream) {
+  MMF_TRY(check_common(X, n, n, d, in_dtype, device_id));
+  if (metric < MMF_DOT || metric > MMF_RBF) { set_error("prep_rows: bad metric %d", metric); return MMF_E_INVALID; }
+  if (operand != MMF_F16 && operand != MMF_BF16) { set_error("prep_rows: operand must be MMF_F16 or MMF_BF16"); return MMF_E_INVALID; }
+  const int dp = scan_bf16_dp(d);
+  if (dp == 0) { set_error("prep_rows: d = %lld is not supported by the 16-bit scan", (long long)d); return MMF_E_UNSUPPORTED; }
+  if (n_pad < n) { set_error("prep_rows: n_pad < n"); return MMF_E_INVALID; }
+  if (n_pad == 0) return MMF_OK;
+  if (!scal || !Z || !zn || !rn || !un || !cb || !maxima || (metric != MMF_COSINE && !max_sq_norm)) {
+    set_error("prep_rows: NULL pointer"); return MMF_E_INVALID;
+  }
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  return launch_prep_half(X, n, d, in_dtype, metric, scal, reinterpret_cast<const uint32_t*>(max_sq_norm), Z, n_pad, dp,
+                          operand == MMF_F16 ? 1 : 0, zn, rn, un, cb, reinterpret_cast<uint32_t*>(maxima),
+                          static_cast<hipStream_t>(hip_stream));
+}
+
+int mmf_simtopk_prepared(const void* X, int64_t n, const void* Y, int64_t m, int64_t d, int in_dtype, int metric,
+                         float lambda, int k, int exclude_self, int64_t row_offset, int64_t col_offset,
+                         const mmf_prepared_side* q, const mmf_prepared_side* c, int64_t m_pad, const float* maxima,
+                         int operand, int64_t* out_idx, float* out_val, const mmf_simtopk_opts* opts,
+                         mmf_simtopk_stats* stats, int device_id, void* hip_stream) {
+  MMF_TRY(check_common(X, n, m, d, in_dtype, device_id));
+  if (!Y || !q || !c || !maxima) { set_error("simtopk_prepared: NULL pointer"); return MMF_E_INVALID; }
+  if (metric < MMF_DOT || metric > MMF_RBF) { set_error("simtopk_prepared: bad metric %d", metric); return MMF_E_INVALID; }
+  if (metric == MMF_RBF && !(lambda > 0.0f)) { set_error("simtopk_prepared: MMF_RBF needs lambda > 0"); return MMF_E_INVALID; }
+  if (operand != MMF_F16 && operand != MMF_BF16) { set_error("simtopk_prepared: bad operand"); return MMF_E_INVALID; }
+  if (k < 1) { set_error("simtopk_prepared: k must be >= 1"); return MMF_E_INVALID; }
+  if (m_pad < m || (m_pad % 256) != 0) { set_error("simtopk_prepared: m_pad must be a multiple of 256 and >= m"); return MMF_E_INVALID; }
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (n == 0) return MMF_OK;
+  {
+    const bool overlap = exclude_self && (row_offset < col_offset + m) && (row_offset + n > col_offset);
+    if (k > m - (overlap ? 1 : 0)) { set_error("simtopk_prepared: k exceeds the admissible columns"); return MMF_E_INVALID; }
+  }
+  const int kk = k + (exclude_self ? 1 : 0);
+  if (!scan_bf16_supported(d, kk, in_dtype)) { set_error("simtopk_prepared: d = %lld / k = %d not supported by the 16-bit scan", (long long)d, k); return MMF_E_UNSUPPORTED; }
+  const int cap = scan_f32_cap(kk);
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  FastTail ft(n, m, kk, cap, opts ? opts->col_splits : 0);
+  Workspace ws;
+  MMF_TRY(get_workspace(device_id, s, ft.bytes(), &ws));
+  ft.carve(ws);
+  FastOperands fo{static_cast<const uint16_t*>(q->Z), static_cast<const uint16_t*>(c->Z), q->scal, c->scal, q->zn, q->rn, q->un,
+                  c->cb, reinterpret_cast<const uint32_t*>(maxima), m_pad, scan_bf16_dp(d), operand == MMF_F16};
+  return ft.run(X, n, Y, m, d, in_dtype, metric, lambda, k, exclude_self, row_offset, col_offset, fo, out_idx, out_val,
+                opts && opts->profile, opts ? opts->select_wait_event : nullptr, stats,
+                operand == MMF_F16 ? MMF_PREC_FAST : MMF_PREC_FAST_BF16, s);
 }
 
 int mmf_topk_merge(const int64_t* ia, const float* va, const int64_t* ib, const float* vb, int64_t n, int k,

@@ -359,12 +359,22 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
           atomicAdd(a.dbg + 4, (unsigned long long)lanes_hit);
         }
       }
+      unsigned long long ts0 = 0;
+      if (a.debug & 16) ts0 = __builtin_amdgcn_s_memtime();
       if (cold) list.template offer_tile<false>(acc, id0, half, a.kk, margin);   // cold start
       else list.offer_tile_warm(acc, id0, half, a.kk, margin);
+      if ((a.debug & 16) && lane == 0) {
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - ts0;
+        atomicAdd(a.dbg + (cold ? 4 : 5), dt);
+        atomicAdd(a.dbg + (cold ? 6 : 7), 1ull);
+      }
     }
     if ((a.debug & 8) && lane == 0) atomicAdd(a.dbg + 5, 1ull);   // tiles
   };
 
+  // diagnostic build of the loop (MMF_SCAN_DEBUG & 16): s_memtime stamps, shares only
+  unsigned long long tw = 0, tf = 0, tc = 0, t0s = 0, t1s = 0, t2s = 0, t3s = 0;
+  const bool stamps = (a.debug & 16) != 0;
   int stage = 0;
   f32x16 acc_prev;
 #pragma unroll
@@ -380,11 +390,14 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
       else if (allow == 4) __builtin_amdgcn_s_waitcnt(0x0F74);
       else __builtin_amdgcn_s_waitcnt(0x0F75);
     }
+    if (stamps) t0s = __builtin_amdgcn_s_memtime();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();   // tile t visible to all; everyone is done READING tile t-1
     asm volatile("" ::: "memory");
+    if (stamps) t1s = __builtin_amdgcn_s_memtime();
 
     filter(acc_prev, t - 1);
+    if (stamps) t2s = __builtin_amdgcn_s_memtime();
 
     const bool more = (t + 2 < Ti);
     int s2 = stage + 2;
@@ -398,9 +411,17 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
     if (wave == ((t + 2) & 7)) issue_bias(more ? bsrc : cb0, s2);
     tsrc += TILEB;
     bsrc += B_CT * 4;
+    if (stamps) {
+      asm volatile("" :: "v"(acc_prev[0]));          // the chain's result must exist before the stamp
+      t3s = __builtin_amdgcn_s_memtime();
+      tw += t1s - t0s; tf += t2s - t1s; tc += t3s - t2s;
+    }
 
     ++stage;
     if (stage == B_STAGES) stage = 0;
+  }
+  if (stamps && lane == 0) {
+    atomicAdd(a.dbg + 0, tw); atomicAdd(a.dbg + 1, tf); atomicAdd(a.dbg + 2, tc); atomicAdd(a.dbg + 3, (unsigned long long)Ti);
   }
   if (Ti > 0) filter(acc_prev, Ti - 1);
   __builtin_amdgcn_s_waitcnt(0x0F70);   // the two dummy tiles still in flight
@@ -476,7 +497,7 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
     const char* dbg = getenv("MMF_SCAN_DEBUG");
     a.debug = dbg ? atoi(dbg) : 0;
     a.dbg = nullptr;
-    if (a.debug & 8) {
+    if (a.debug & (8 | 16)) {
       static unsigned long long* dbuf = nullptr;
       if (!dbuf) MMF_HIP(hipMalloc(&dbuf, 64));
       MMF_HIP(hipMemsetAsync(dbuf, 0, 64, s));
@@ -499,6 +520,16 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
     case 256: rc = launch_b16_t<16>(a, f16, grid, s); break;
     case 512: rc = launch_b16_t<32>(a, f16, grid, s); break;
     default: set_error("scan_b16: unsupported padded dim %d", dp);
+  }
+  if (rc == MMF_OK && (a.debug & 16)) {
+    unsigned long long h[8];
+    MMF_HIP(hipMemcpyAsync(h, a.dbg, 64, hipMemcpyDeviceToHost, s));
+    MMF_HIP(hipStreamSynchronize(s));
+    const double tiles = (double)h[3];
+    fprintf(stderr, "[mmf scan stamps] per wave-tile cycles: barrier-wait %.0f  filter %.0f  chain(+DMA issue) %.0f  (sum %.0f)\n",
+            h[0] / tiles, h[1] / tiles, h[2] / tiles, (h[0] + h[1] + h[2]) / tiles);
+    fprintf(stderr, "[mmf scan stamps] list code: cold entries %llu x %.0f cycles, warm entries %llu x %.0f cycles\n",
+            h[6], h[6] ? (double)h[4] / h[6] : 0.0, h[7], h[7] ? (double)h[5] / h[7] : 0.0);
   }
   if (rc == MMF_OK && (a.debug & 8)) {
     unsigned long long h[8];

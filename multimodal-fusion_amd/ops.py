@@ -61,7 +61,7 @@ def simtopk(X: torch.Tensor, Y: Optional[torch.Tensor] = None, *, metric="cosine
     m = n if Y is None else Y.shape[0]
     idx = torch.empty((n, k), dtype=torch.int64, device=X.device)
     val = torch.empty((n, k), dtype=torch.float32, device=X.device)
-    opts = _lib.SimtopkOpts(_lib.PRECISIONS[precision], int(profile), int(col_splits), 0)
+    opts = _lib.SimtopkOpts(_lib.PRECISIONS[precision], int(profile), int(col_splits), 0, None)
     stats = _lib.SimtopkStats()
     rc = _lib.lib().mmf_simtopk_ex(_p(X), n, _p(Y), m, d, _DT[X.dtype], _metric(metric), float(lam), int(k),
                                    int(bool(exclude_self)), int(row_offset), int(col_offset), _p(idx), _p(val),
@@ -164,3 +164,68 @@ def threshold_edges(K: torch.Tensor, threshold: float) -> Tuple[torch.Tensor, to
         _lib.check(L.mmf_threshold_edges(_p(K), n, float(threshold), _p(ei), _p(ew), E, _p(cnt), dev, st),
                    "mmf_threshold_edges")
     return ei, ew
+
+
+# ---------------------------------------------------------------------------------------------------
+# phase API of the fast path (row-sharded multi-GPU driver, distributed.py)
+# ---------------------------------------------------------------------------------------------------
+_OPERAND = {"f16": _lib.F16, "bf16": _lib.BF16}
+
+
+def padded_dim(d: int) -> int:
+    """Padded feature dim of the 16-bit operands; 0 when d is not supported by the 16-bit scan."""
+    return int(_lib.lib().mmf_padded_dim(int(d)))
+
+
+def row_scalars(X: torch.Tensor, metric, scal: torch.Tensor, max_sq_norm: Optional[torch.Tensor] = None) -> None:
+    """scal[i] = canonical n_i (clamped norm for cosine); max_sq_norm[0] is raised to max n_i."""
+    X = _feat(X, "row_scalars X")
+    _need_gpu(X, "row_scalars")
+    rc = _lib.lib().mmf_row_scalars(_p(X), X.shape[0], X.shape[1], _DT[X.dtype], _metric(metric), _p(scal),
+                                    _p(max_sq_norm), X.device.index or 0, _stream(X.device))
+    _lib.check(rc, "mmf_row_scalars")
+
+
+def prep_rows(X: torch.Tensor, metric, operand: str, scal: torch.Tensor, max_sq_norm: Optional[torch.Tensor],
+              Z: torch.Tensor, zn: torch.Tensor, rn: torch.Tensor, un: torch.Tensor, cb: torch.Tensor,
+              maxima: torch.Tensor) -> None:
+    """16-bit operands + per-row norms of the rows of X into caller-owned buffers (mmf_prep_rows)."""
+    X = _feat(X, "prep_rows X")
+    _need_gpu(X, "prep_rows")
+    n_pad = Z.shape[0]
+    for t in (Z, zn, rn, un, cb):
+        if not t.is_contiguous():
+            raise ValueError("prep_rows: output buffers must be contiguous")
+    rc = _lib.lib().mmf_prep_rows(_p(X), X.shape[0], X.shape[1], _DT[X.dtype], _metric(metric), _OPERAND[operand],
+                                  _p(scal), _p(max_sq_norm), _p(Z), n_pad, _p(zn), _p(rn), _p(un), _p(cb), _p(maxima),
+                                  X.device.index or 0, _stream(X.device))
+    _lib.check(rc, "mmf_prep_rows")
+
+
+def simtopk_prepared(X: torch.Tensor, Y: torch.Tensor, q: dict, c: dict, m_pad: int, maxima: torch.Tensor, *,
+                     operand: str = "f16", metric="cosine", lam: float = 1.0, k: int = 5, exclude_self: bool = True,
+                     row_offset: int = 0, col_offset: int = 0, profile: bool = False, col_splits: int = 0,
+                     wait_event: Optional[torch.cuda.Event] = None, return_stats: bool = False):
+    """Scan on prepared operands + exact re-rank (mmf_simtopk_prepared).  q / c: dicts with the tensors
+    Z, scal, zn, rn, un, cb of the query / candidate side.  wait_event: recorded when the f32 rows of
+    X / Y are complete; the stream waits for it only after the scan."""
+    _need_gpu(X, "simtopk_prepared")
+    n, d = X.shape
+    m = Y.shape[0]
+    idx = torch.empty((n, k), dtype=torch.int64, device=X.device)
+    val = torch.empty((n, k), dtype=torch.float32, device=X.device)
+
+    def side(dd):
+        return _lib.PreparedSide(*(ctypes.c_void_p(dd[key].data_ptr()) for key in ("Z", "scal", "zn", "rn", "un", "cb")))
+    qs, cs = side(q), side(c)
+    ev = ctypes.c_void_p(wait_event.cuda_event) if wait_event is not None else None
+    opts = _lib.SimtopkOpts(_lib.PRECISIONS["fast"], int(profile), int(col_splits), 0, ev)
+    stats = _lib.SimtopkStats()
+    rc = _lib.lib().mmf_simtopk_prepared(_p(X), n, _p(Y), m, d, _DT[X.dtype], _metric(metric), float(lam), int(k),
+                                         int(bool(exclude_self)), int(row_offset), int(col_offset), ctypes.byref(qs),
+                                         ctypes.byref(cs), int(m_pad), _p(maxima), _OPERAND[operand], _p(idx), _p(val),
+                                         ctypes.byref(opts), ctypes.byref(stats), X.device.index or 0, _stream(X.device))
+    _lib.check(rc, "mmf_simtopk_prepared")
+    if return_stats:
+        return idx, val, stats.as_dict()
+    return idx, val

@@ -133,3 +133,38 @@ def test_c5_fp16_features_d1024(mmf):
     assert st["precision_used"] == 2
     check_properties(idx, val, 20000, 20000, 0, True)
     check_against_oracle_blocks(Xh.float(), None, idx, val, 5, True)
+
+
+@pytest.mark.parametrize("metric", ["cosine", "neg_sq_l2", "dot"])
+def test_phase_api_equals_single_call(mmf, metric):
+    """mmf_row_scalars + mmf_prep_rows per shard, concatenated as an all-gather would, then
+    mmf_simtopk_prepared for one shard == the rows of the single-call result, bit for bit."""
+    N, d, P, k = 8192, 256, 4, 5
+    X = make(N, d, 31) * (1.0 if metric == "cosine" else 3.0)
+    full_i, full_v = mmf.simtopk(X, metric=metric, k=k)
+    ops = mmf.ops
+    dp = ops.padded_dim(d)
+    rows = N // P
+    maxn = torch.zeros(1, device="cuda")
+    scal = [torch.empty(rows, device="cuda") for _ in range(P)]
+    for r in range(P):
+        ops.row_scalars(X[r * rows:(r + 1) * rows], metric, scal[r], maxn)      # shared maximum == all-reduce MAX
+    m_pad = (N + 255) // 256 * 256
+    Z = torch.zeros((m_pad + 256, dp), dtype=torch.float16, device="cuda")
+    side = {n_: torch.full((m_pad + 256,), float("-inf") if n_ == "cb" else 0.0, device="cuda") for n_ in ("scal", "zn", "rn", "un", "cb")}
+    max4 = torch.zeros(4, device="cuda")
+    for r in range(P):
+        sl = slice(r * rows, (r + 1) * rows)
+        z = torch.empty((rows, dp), dtype=torch.float16, device="cuda")
+        zn, rn, un, cb = (torch.empty(rows, device="cuda") for _ in range(4))
+        ops.prep_rows(X[sl], metric, "f16", scal[r], maxn, z, zn, rn, un, cb, max4)
+        Z[sl] = z
+        side["scal"][sl], side["zn"][sl], side["rn"][sl], side["un"][sl], side["cb"][sl] = scal[r], zn, rn, un, cb
+    for r in (0, 2, 3):
+        lo, hi = r * rows, (r + 1) * rows
+        q = dict(Z=Z[lo:], **{n_: side[n_][lo:] for n_ in side})
+        ev = torch.cuda.Event()
+        ev.record()
+        i, v, st = ops.simtopk_prepared(X[lo:hi], X, q, dict(Z=Z, **side), m_pad, max4, metric=metric, k=k,
+                                        exclude_self=True, row_offset=lo, wait_event=ev, return_stats=True)
+        assert torch.equal(i, full_i[lo:hi]) and torch.equal(v, full_v[lo:hi]), (metric, r)
