@@ -64,8 +64,9 @@ int launch_prep_half(const void* X, int64_t n, int64_t d, int dtype, int metric,
                      hipStream_t s);
 int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float* q_zn, const float* q_rn,
                     const float* q_un, const uint32_t* maxima, int64_t n_rows, int64_t m, int64_t m_pad, int dp,
-                    int64_t d, bool f16, int metric, int kk, int col_splits, const CandLists& L, hipStream_t s,
-                    int* grid_out);
+                    int64_t d, bool f16, int metric, int kk, int col_splits, const CandLists& L, void* scratch,
+                    hipStream_t s, int* grid_out);
+size_t scan_b16_scratch_bytes(int64_t n_rows, int col_splits);
 
 static int check_common(const void* X, int64_t n, int64_t m, int64_t d, int in_dtype, int device_id) {
   if (device_id < 0) {
@@ -133,6 +134,7 @@ struct FastTail {
   CandLists L, FL;
   int32_t *fail_rows = nullptr, *fb_fail_rows = nullptr;
   uint32_t *fail_count = nullptr, *cand_total = nullptr, *fb_fail_count = nullptr;
+  char* scan_scratch = nullptr;
 
   FastTail(int64_t n_, int64_t m_, int kk_, int cap_, int forced_splits) : n(n_), m(m_), kk(kk_), cap(cap_) {
     bcap = scan_bf16_cap();
@@ -149,7 +151,7 @@ struct FastTail {
   size_t bytes() const {
     return ws_bytes((size_t)n * lists, 4) + ws_bytes((size_t)n * lists * bcap, 4) + 2 * ws_bytes(n, 4) + ws_bytes(4, 4) +
            ws_bytes(256, 4) + ws_bytes((size_t)FB * fb_lists, 4) + ws_bytes((size_t)FB * fb_lists * cap, 4) +
-           2 * ws_bytes(FB, 4) + ws_bytes(4, 4);
+           2 * ws_bytes(FB, 4) + ws_bytes(4, 4) + ws_bytes(scan_b16_scratch_bytes(n, splits), 1);
   }
   void carve(Workspace& ws) {
     L.cnt = ws.take<uint32_t>((size_t)n * lists);
@@ -165,6 +167,7 @@ struct FastTail {
     FL.lists = fb_lists; FL.cap = cap;
     fb_fail_rows = ws.take<int32_t>(FB);
     fb_fail_count = ws.take<uint32_t>(4);
+    scan_scratch = ws.take<char>(scan_b16_scratch_bytes(n, splits));
   }
   int run(const void* X, int64_t n_, const void* Y, int64_t m_, int64_t d, int in_dtype, int metric, float lambda, int k,
           int exclude_self, int64_t row_offset, int64_t col_offset, const FastOperands& fo, int64_t* out_idx,
@@ -176,7 +179,7 @@ struct FastTail {
     int grid = 0;
     MMF_TRY(t_scan.start(profile, s));
     MMF_TRY(launch_scan_b16(fo.ZQ, fo.ZC, fo.c_cb, fo.q_zn, fo.q_rn, fo.q_un, fo.max_c, n, m, fo.m_pad_tiles, fo.dp, d, fo.f16,
-                            metric, kk, splits, L, s, &grid));
+                            metric, kk, splits, L, scan_scratch, s, &grid));
     MMF_TRY(t_scan.stop(s));
     // the f32 rows are first touched here: a caller that is still receiving them (overlapped
     // all-gather) hands in the event that marks their arrival

@@ -369,6 +369,148 @@ struct LaneList {
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// SlotList — the candidate list of the 16-bit scan (approximate keys only).
+//
+// Keys live in LDS (entry e of thread t at keys[e * NT + t]); the low 4 mantissa bits of a stored
+// key carry a SLOT number, and the candidate's column id sits in a lane-private GLOBAL slot array
+// (idslot[s * NT + t]) that is written once on push and read once when the scan ends.  Compaction
+// therefore sorts / filters bare keys in LDS and never touches global memory.  The <= 15 ulp the
+// slot bits perturb a key by are part of the error margin (scan kernel, E1).
+// Thresholds, partner-lane merge and the audited-loss rule are those of LaneList.
+// ---------------------------------------------------------------------------------------------
+template <int CAP, int NT>
+struct SlotList {
+  static_assert(CAP <= 16, "4 slot bits");
+  float* keys;        // LDS, offset by threadIdx.x
+  uint32_t* idslot;   // global, offset by threadIdx.x
+  int cnt;
+  uint32_t used;      // bit s set: slot s holds the id of a live entry
+  float thr;
+  float lost;
+  uint32_t overflow;
+
+  __device__ __forceinline__ void init(float* k, uint32_t* ids) {
+    keys = k; idslot = ids; cnt = 0; used = 0; thr = -kFltMax; lost = kNegInf; overflow = 0;
+  }
+  __device__ __forceinline__ void finish() {
+    if (lost >= thr) overflow = 1;
+  }
+  __device__ __forceinline__ void push(float key, uint32_t id) {   // requires cnt < CAP
+    const int sl = __builtin_ctz(~used);
+    idslot[sl * NT] = id;
+    keys[cnt * NT] = __uint_as_float((__float_as_uint(key) & ~15u) | (uint32_t)sl);
+    used |= 1u << sl;
+    ++cnt;
+  }
+  __device__ __forceinline__ uint32_t id_of(int e) const {          // entry e -> column id (global read)
+    return idslot[(__float_as_uint(keys[e * NT]) & 15u) * NT];
+  }
+  __device__ __forceinline__ void raise_thr(float t, float margin) {
+    const float nthr = (t == kNegInf) ? -kFltMax : (t - margin);
+    if (nthr > thr) thr = nthr;
+  }
+
+  // wave-wide; leaves at least two free slots (what it drops for that is recorded in `lost`)
+  __device__ __forceinline__ void compact(int kk, float margin) {
+    float k[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) k[e] = ((e < CAP) && (e < cnt)) ? keys[(e < CAP ? e : 0) * NT] : kNegInf;
+#pragma unroll
+    for (int size = 2; size <= 16; size <<= 1) {
+#pragma unroll
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int j = i ^ stride;
+          if (j > i) {
+            const float hi = fmaxf(k[i], k[j]), lo = fminf(k[i], k[j]);
+            if ((i & size) == 0) { k[i] = hi; k[j] = lo; } else { k[i] = lo; k[j] = hi; }
+          }
+        }
+      }
+    }
+    float c[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) c[e] = fmaxf(k[e], __shfl_xor(k[15 - e], 32));
+#pragma unroll
+    for (int stride = 8; stride > 0; stride >>= 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int j = i ^ stride;
+        if (j > i) {
+          const float hi = fmaxf(c[i], c[j]), lo = fminf(c[i], c[j]);
+          c[i] = hi; c[j] = lo;
+        }
+      }
+    }
+    float t = kNegInf;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      if (e == kk - 1) t = c[e];
+    }
+    raise_thr(t, margin);
+    int keep = 0;
+#pragma unroll
+    for (int e = 0; e < CAP; ++e) keep += ((e < cnt) && (k[e] >= thr)) ? 1 : 0;
+    float cut = thr;
+    if (keep >= CAP - 1) {       // crowded: lossy truncation to the CAP-2 best
+      lost = fmaxf(lost, k[CAP - 2]);
+      thr = fmaxf(thr, lost);
+      cut = k[CAP - 3];
+    }
+    int w = 0;
+    uint32_t nused = 0;
+    for (int e = 0; e < cnt; ++e) {     // in-place filter of the LDS keys, lane-private
+      const float ke = keys[e * NT];
+      if (ke >= cut) {
+        if (w < CAP - 2) { keys[w * NT] = ke; nused |= 1u << (__float_as_uint(ke) & 15u); ++w; }
+        else lost = fmaxf(lost, ke);
+      }
+    }
+    thr = fmaxf(thr, lost);
+    used = nused;
+    cnt = w;
+  }
+
+  // robust path (cold start): never drops, compacts whenever a list fills
+  __device__ __forceinline__ void offer_tile_cold(const f32x16& v, uint32_t id0, int half, int kk, float margin) {
+#pragma unroll 1
+    for (int r = 0; r < 16; ++r) {
+      const float x = v[r];
+      bool hit = x >= thr;
+      if (__any(hit)) {
+        if (__any(hit && cnt >= CAP)) {
+          compact(kk, margin);
+          hit = x >= thr;
+        }
+        if (hit) {
+          if (cnt < CAP) push(x, id0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * half));
+          else { lost = fmaxf(lost, x); thr = fmaxf(thr, lost); }
+        }
+      }
+    }
+  }
+
+  // warm lists: one compaction site, then 16 straight-line tests; a hit that still finds its list full
+  // is dropped under the audited-loss rule
+  __device__ __forceinline__ void offer_tile_warm(const f32x16& v, uint32_t id0, int half, int kk, float margin) {
+    if (__any(cnt >= CAP - 1)) compact(kk, margin);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float x = v[r];
+      if (x >= thr) {
+        if (cnt < CAP) {
+          push(x, id0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * half));
+        } else {
+          lost = fmaxf(lost, x);
+          thr = fmaxf(thr, lost);
+        }
+      }
+    }
+  }
+};
+
 __device__ __forceinline__ float max16(const f32x16& v) {
   float a = fmaxf(fmaxf(v[0], v[1]), v[2]);
   float b = fmaxf(fmaxf(v[3], v[4]), v[5]);

@@ -35,7 +35,7 @@ constexpr int B_NT = 512;
 constexpr int B_WAVES = 8;
 constexpr int B_QT = 256;
 constexpr int B_CT = 32;
-constexpr int B_STAGES = 3;
+constexpr int B_STAGES = 4;   // two PAIRS of tiles: one pair is read while the other is filled
 constexpr int B_CAP = 12;
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -169,6 +169,7 @@ struct ScanB16Args {
   int d;
   int debug;                 // MMF_SCAN_DEBUG: 1 = skip the filter / list code (timing only), 8 = count events
   unsigned long long* dbg;   // [8] event counters when debug & 8
+  uint32_t* lids;            // lane-private id slots: [grid][16][B_NT] (global, written on push, read once at the end)
   uint32_t* cand_cnt; uint32_t* cand_ids; uint32_t* overflow;
 };
 
@@ -176,7 +177,7 @@ struct ScanB16Args {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), \
                                    (__attribute__((address_space(3))) void*)(lptr), size, 0, 0)
 
-template <int KS, bool F16>
+template <int KS, bool F16, bool DBG>
 __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
   constexpr int ROWB = KS * 32;                 // bytes per candidate row in LDS (= DP * 2)
   constexpr int TILEB = B_CT * ROWB;            // bytes per tile
@@ -186,8 +187,10 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* tiles = smem;                                                  // [B_STAGES][TILEB]
   float* cbs = reinterpret_cast<float*>(smem + B_STAGES * TILEB);      // [B_STAGES][64]
+  // Candidate lists (SlotList, mmf_dev.h): approximate keys in LDS, column ids in a global slot block of
+  // this workgroup — leaving most of LDS to the tile ring is what buys the fourth stage.
   float* lkeys = cbs + B_STAGES * 64;                                  // [B_CAP][B_NT]
-  uint32_t* lids = reinterpret_cast<uint32_t*>(lkeys + B_CAP * B_NT);  // [B_CAP][B_NT]
+  uint32_t* lids = a.lids + (size_t)blockIdx.x * (16 * B_NT);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -225,7 +228,8 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
     const float zn = a.q_zn[qpos], rn = a.q_rn[qpos], un = a.q_un[qpos];   // arrays are padded
     const float g_acc = (float)(KS * 16 + 8) * 5.9604645e-8f;
     const float g_chain = (float)(a.d + 2) * 5.9604645e-8f;
-    const float e1 = rn * ZB + un * RB + g_acc * (zn * ZB + CB);
+    // + 2^-19 |G|: the 4 slot bits a stored key carries in its low mantissa bits (SlotList)
+    const float e1 = rn * ZB + un * RB + (g_acc + 1.9073486e-6f) * (zn * ZB + CB);
     float e2;
     if (a.metric == MMF_DOT) e2 = g_chain * un * UB;
     else if (a.metric == MMF_COSINE) e2 = (g_chain + 4.7683716e-7f) * un * UB * 1.01f;
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
     margin = 2.0f * (e1 + e2) * 1.001f + 1e-30f;
   }
 
-  LaneList<B_CAP, B_NT> list;
+  SlotList<B_CAP, B_NT> list;
   list.init(lkeys + tid, lids + tid);
   if (!qvalid) list.thr = __builtin_huge_valf();
 
@@ -267,7 +271,6 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
     const int src_chunk = (chunk & ~15) | ((chunk ^ r) & 15);
     src_off[i] = (uint32_t)(r * ROWB + src_chunk * 16);
   }
-  const uint32_t lane4 = (uint32_t)lane * 4u;
   const char* zc0 = reinterpret_cast<const char*>(a.ZC) + t_begin * (int64_t)TILEB;          // tile 0 of my range
   const char* cb0 = reinterpret_cast<const char*>(a.cb + t_begin * B_CT);
   auto issue_piece = [&](const char* tsrc, int stage, int i) {
@@ -275,11 +278,12 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
   };
   // the 32 biases of a tile: one 4-byte DMA by lanes 0..31 of the wave whose turn it is
   auto issue_bias = [&](const char* bsrc, int stage) {
-    if (lane < 32) MMF_GLDS(bsrc + lane4, cbs + stage * 64, 4);
+    const uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // lane id, no live VGPR
+    if (l < 32) MMF_GLDS(bsrc + l * 4u, cbs + stage * 64, 4);
   };
 
   const int Ti = (int)T;
-  if (Ti > 0) {
+  if (Ti > 0) {   // pair 0 = tiles 0, 1 -> stages 0, 1
 #pragma unroll
     for (int i = 0; i < PPW; ++i) issue_piece(zc0, 0, i);
     if (wave == 0) issue_bias(cb0, 0);
@@ -339,11 +343,11 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
   // placed before the barrier it would hold all eight waves, and their matrix pipes, at the barrier.
   auto filter = [&](const f32x16& acc, int tt) {
     const float mx = max16(acc);
-    if (!(a.debug & 1) && __any(mx >= list.thr)) {
+    if (!(DBG && (a.debug & 1)) && __any(mx >= list.thr)) {
       const uint32_t id0 = id_base + (uint32_t)tt * B_CT;
       // robust (never dropping) path while thresholds are still forming: first 32 tiles of the range
       const bool cold = (tt < 32) || __any(list.thr == -kFltMax);
-      if (a.debug & 8) {
+      if (DBG && (a.debug & 8)) {
         const bool willc = __any(list.cnt >= B_CAP - 1);
         int nh = 0;
 #pragma unroll
@@ -360,78 +364,78 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
         }
       }
       unsigned long long ts0 = 0;
-      if (a.debug & 16) ts0 = __builtin_amdgcn_s_memtime();
-      if (cold) list.template offer_tile<false>(acc, id0, half, a.kk, margin);   // cold start
+      if (DBG && (a.debug & 16)) ts0 = __builtin_amdgcn_s_memtime();
+      if (cold) list.offer_tile_cold(acc, id0, half, a.kk, margin);
       else list.offer_tile_warm(acc, id0, half, a.kk, margin);
-      if ((a.debug & 16) && lane == 0) {
+      if (DBG && (a.debug & 16) && lane == 0) {
         const unsigned long long dt = __builtin_amdgcn_s_memtime() - ts0;
         atomicAdd(a.dbg + (cold ? 4 : 5), dt);
         atomicAdd(a.dbg + (cold ? 6 : 7), 1ull);
       }
     }
-    if ((a.debug & 8) && lane == 0) atomicAdd(a.dbg + 5, 1ull);   // tiles
+    if (DBG && (a.debug & 8) && lane == 0) atomicAdd(a.dbg + 5, 1ull);   // tiles
   };
 
-  // diagnostic build of the loop (MMF_SCAN_DEBUG & 16): s_memtime stamps, shares only
+  // Main loop: TWO tiles per barrier.  Iteration j reads the pair of stages holding tiles 2j, 2j+1 and
+  // fills the other pair with tiles 2j+2, 2j+3 (DMA pieces issued inside the two MFMA chains), so at the
+  // top of an iteration everything this wave has in flight is exactly what the iteration needs:
+  // vmcnt(0), barrier.  Past the end of the range the DMA re-fetches tile 0 into a stage nobody reads.
   unsigned long long tw = 0, tf = 0, tc = 0, t0s = 0, t1s = 0, t2s = 0, t3s = 0;
-  const bool stamps = (a.debug & 16) != 0;
-  int stage = 0;
+  const bool stamps = DBG && (a.debug & 16) != 0;
   f32x16 acc_prev;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc_prev[r] = kNegInf;      // "tile -1": nothing can hit
-  for (int t = 0; t < Ti; ++t) {
-    // my pieces of tile t have landed once at most the pieces of tile t+1 are outstanding
-    {
-      const int allow = PPW + ((wave == ((t + 1) & 7)) ? 1 : 0);
-      // vmcnt(N) alone: expcnt = 7 and lgkmcnt = 15 mean "no wait" (gfx9 encoding)
-      if (allow == 1) __builtin_amdgcn_s_waitcnt(0x0F71);
-      else if (allow == 2) __builtin_amdgcn_s_waitcnt(0x0F72);
-      else if (allow == 3) __builtin_amdgcn_s_waitcnt(0x0F73);
-      else if (allow == 4) __builtin_amdgcn_s_waitcnt(0x0F74);
-      else __builtin_amdgcn_s_waitcnt(0x0F75);
-    }
+  const int nIter = (Ti + 1) >> 1;
+  for (int j = 0; j < nIter; ++j) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) alone (expcnt 7, lgkmcnt 15 = no wait)
     if (stamps) t0s = __builtin_amdgcn_s_memtime();
     asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // tile t visible to all; everyone is done READING tile t-1
+    __builtin_amdgcn_s_barrier();   // this pair is visible to all; everyone is done READING the other pair
     asm volatile("" ::: "memory");
     if (stamps) t1s = __builtin_amdgcn_s_memtime();
 
-    filter(acc_prev, t - 1);
+    const int t0 = 2 * j, t1 = t0 + 1;
+    filter(acc_prev, t0 - 1);
     if (stamps) t2s = __builtin_amdgcn_s_memtime();
 
-    const bool more = (t + 2 < Ti);
-    int s2 = stage + 2;
-    if (s2 >= B_STAGES) s2 -= B_STAGES;
-    const char* src = more ? tsrc : zc0;
-    const char* tb = tiles + stage * TILEB;
-    const float* cbt = cbs + stage * 64;
+    const int sa = (j & 1) * 2, sb = sa + 1, na = 2 - sa, nb = na + 1;
+    const bool more0 = (t0 + 2 < Ti), more1 = (t1 + 2 < Ti);
+    const char* src0 = more0 ? tsrc : zc0;
+    const char* src1 = more1 ? tsrc + TILEB : zc0;
 
-    if (upper) acc_prev = tile_body(std::true_type{}, tb, cbt, src, s2);
-    else acc_prev = tile_body(std::false_type{}, tb, cbt, src, s2);
-    if (wave == ((t + 2) & 7)) issue_bias(more ? bsrc : cb0, s2);
-    tsrc += TILEB;
-    bsrc += B_CT * 4;
+    f32x16 acc0;
+    if (upper) acc0 = tile_body(std::true_type{}, tiles + sa * TILEB, cbs + sa * 64, src0, na);
+    else acc0 = tile_body(std::false_type{}, tiles + sa * TILEB, cbs + sa * 64, src0, na);
+    if (wave == ((t0 + 2) & 7)) issue_bias(more0 ? bsrc : cb0, na);
+    filter(acc0, t0);               // no barrier nearby: only this wave waits for its own list code
+
+    if (upper) acc_prev = tile_body(std::true_type{}, tiles + sb * TILEB, cbs + sb * 64, src1, nb);
+    else acc_prev = tile_body(std::false_type{}, tiles + sb * TILEB, cbs + sb * 64, src1, nb);
+    if (wave == ((t1 + 2) & 7)) issue_bias(more1 ? bsrc + B_CT * 4 : cb0, nb);
+    if (t1 >= Ti) {                 // odd range: the second tile of the last pair is a dummy
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_prev[r] = kNegInf;
+    }
+    tsrc += 2 * TILEB;
+    bsrc += 2 * B_CT * 4;
     if (stamps) {
       asm volatile("" :: "v"(acc_prev[0]));          // the chain's result must exist before the stamp
       t3s = __builtin_amdgcn_s_memtime();
       tw += t1s - t0s; tf += t2s - t1s; tc += t3s - t2s;
     }
-
-    ++stage;
-    if (stage == B_STAGES) stage = 0;
   }
   if (stamps && lane == 0) {
     atomicAdd(a.dbg + 0, tw); atomicAdd(a.dbg + 1, tf); atomicAdd(a.dbg + 2, tc); atomicAdd(a.dbg + 3, (unsigned long long)Ti);
   }
-  if (Ti > 0) filter(acc_prev, Ti - 1);
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // the two dummy tiles still in flight
+  if (Ti > 0) filter(acc_prev, 2 * nIter - 1);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // the dummy tiles still in flight
 
-  list.template compact<false>(a.kk, margin);
+  list.compact(a.kk, margin);
   list.finish();
   if (qvalid) {
     const int64_t lbase = qpos * (2 * a.col_splits) + 2 * split + half;
     a.cand_cnt[lbase] = (uint32_t)list.cnt;
-    for (int e = 0; e < list.cnt; ++e) a.cand_ids[lbase * B_CAP + e] = list.ids[e * B_NT];
+    for (int e = 0; e < list.cnt; ++e) a.cand_ids[lbase * B_CAP + e] = list.id_of(e);
     if (list.overflow) atomicOr(a.overflow + qpos, 1u);
   }
 }
@@ -466,7 +470,21 @@ int launch_prep_half(const void* X, int64_t n, int64_t d, int dtype, int metric,
 }
 
 static size_t scan_b16_lds(int ks) {
-  return (size_t)B_STAGES * (B_CT * ks * 32) + (size_t)B_STAGES * 64 * 4 + (size_t)B_CAP * B_NT * 8;
+  return (size_t)B_STAGES * (B_CT * ks * 32) + (size_t)B_STAGES * 64 * 4 + (size_t)B_CAP * B_NT * 4;
+}
+
+static int64_t scan_b16_grid(int64_t n_rows, int col_splits) {
+  const int64_t row_blocks = (n_rows + B_QT - 1) / B_QT;
+  if (col_splits <= 8) {
+    const int per = 8 / col_splits;                       // row blocks per group of 8 block ids
+    return ((row_blocks + per - 1) / per) * 8;
+  }
+  return row_blocks * col_splits;                         // col_splits multiple of 8: exact
+}
+
+// bytes of the global id-slot scratch ([grid][16][B_NT] u32) a launch needs
+size_t scan_b16_scratch_bytes(int64_t n_rows, int col_splits) {
+  return (size_t)scan_b16_grid(n_rows, col_splits) * 16 * B_NT * 4 + 256;
 }
 
 template <int KS>
@@ -478,15 +496,19 @@ static int launch_b16_t(const ScanB16Args& a, bool f16, int64_t grid, hipStream_
     MMF_LAUNCH_CHECK();
     return MMF_OK;
   };
-  if (f16) return go(scan_b16_kernel<KS, true>);
-  return go(scan_b16_kernel<KS, false>);
+  if (a.debug != 0) {   // instrumented build of the same kernel (MMF_SCAN_DEBUG)
+    if (f16) return go(scan_b16_kernel<KS, true, true>);
+    return go(scan_b16_kernel<KS, false, true>);
+  }
+  if (f16) return go(scan_b16_kernel<KS, true, false>);
+  return go(scan_b16_kernel<KS, false, false>);
 }
 
 // col_splits must be a power of two.  Lists are indexed by query position, cap = B_CAP.
 int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float* q_zn, const float* q_rn,
                     const float* q_un, const uint32_t* maxima, int64_t n_rows, int64_t m, int64_t m_pad, int dp,
-                    int64_t d, bool f16, int metric, int kk, int col_splits, const CandLists& L, hipStream_t s,
-                    int* grid_out) {
+                    int64_t d, bool f16, int metric, int kk, int col_splits, const CandLists& L, void* scratch,
+                    hipStream_t s, int* grid_out) {
   ScanB16Args a{};
   a.ZQ = ZQ; a.ZC = ZC; a.cb = cb; a.q_zn = q_zn; a.q_rn = q_rn; a.q_un = q_un; a.maxima = maxima;
   a.n_rows = n_rows; a.m = m; a.tiles_total = m_pad / B_CT;
@@ -505,14 +527,8 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
     }
   }
   a.cand_cnt = L.cnt; a.cand_ids = L.ids; a.overflow = L.overflow;
-  int64_t blocks = a.row_blocks * col_splits;
-  int64_t grid;
-  if (col_splits <= 8) {
-    const int per = 8 / col_splits;                       // row blocks per group of 8 block ids
-    grid = ((a.row_blocks + per - 1) / per) * 8;
-  } else {
-    grid = blocks;                                        // col_splits multiple of 8: exact
-  }
+  const int64_t grid = scan_b16_grid(n_rows, col_splits);
+  a.lids = reinterpret_cast<uint32_t*>(scratch);
   if (grid_out) *grid_out = (int)grid;
   int rc = MMF_E_INTERNAL;
   switch (dp) {
