@@ -66,7 +66,8 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
                     const float* q_un, const uint32_t* maxima, int64_t n_rows, int64_t m, int64_t m_pad, int dp,
                     int64_t d, bool f16, int metric, int kk, int col_splits, const CandLists& L, void* scratch,
                     hipStream_t s, int* grid_out);
-size_t scan_b16_scratch_bytes(int64_t n_rows, int col_splits);
+size_t scan_b16_scratch_bytes(int64_t n_rows, int col_splits, int dp);
+int scan_b16_queries_per_block(int dp);
 
 static int check_common(const void* X, int64_t n, int64_t m, int64_t d, int in_dtype, int device_id) {
   if (device_id < 0) {
@@ -136,9 +137,11 @@ struct FastTail {
   uint32_t *fail_count = nullptr, *cand_total = nullptr, *fb_fail_count = nullptr;
   char* scan_scratch = nullptr;
 
-  FastTail(int64_t n_, int64_t m_, int kk_, int cap_, int forced_splits) : n(n_), m(m_), kk(kk_), cap(cap_) {
+  int dp;
+  FastTail(int64_t n_, int64_t m_, int kk_, int cap_, int forced_splits, int dp_) : n(n_), m(m_), kk(kk_), cap(cap_), dp(dp_) {
     bcap = scan_bf16_cap();
-    const int64_t row_blocks = (n + 255) / 256, col_tiles = ((m + 255) / 256 * 256) / 32;
+    const int qt = scan_b16_queries_per_block(dp);
+    const int64_t row_blocks = (n + qt - 1) / qt, col_tiles = ((m + 255) / 256 * 256) / 32;
     splits = 1;
     if (forced_splits > 0) { while (splits < forced_splits) splits <<= 1; }
     else { while (row_blocks * splits < 256 && splits < 32) splits <<= 1; }
@@ -151,7 +154,7 @@ struct FastTail {
   size_t bytes() const {
     return ws_bytes((size_t)n * lists, 4) + ws_bytes((size_t)n * lists * bcap, 4) + 2 * ws_bytes(n, 4) + ws_bytes(4, 4) +
            ws_bytes(256, 4) + ws_bytes((size_t)FB * fb_lists, 4) + ws_bytes((size_t)FB * fb_lists * cap, 4) +
-           2 * ws_bytes(FB, 4) + ws_bytes(4, 4) + ws_bytes(scan_b16_scratch_bytes(n, splits), 1);
+           2 * ws_bytes(FB, 4) + ws_bytes(4, 4) + ws_bytes(scan_b16_scratch_bytes(n, splits, dp), 1);
   }
   void carve(Workspace& ws) {
     L.cnt = ws.take<uint32_t>((size_t)n * lists);
@@ -167,7 +170,7 @@ struct FastTail {
     FL.lists = fb_lists; FL.cap = cap;
     fb_fail_rows = ws.take<int32_t>(FB);
     fb_fail_count = ws.take<uint32_t>(4);
-    scan_scratch = ws.take<char>(scan_b16_scratch_bytes(n, splits));
+    scan_scratch = ws.take<char>(scan_b16_scratch_bytes(n, splits, dp));
   }
   int run(const void* X, int64_t n_, const void* Y, int64_t m_, int64_t d, int in_dtype, int metric, float lambda, int k,
           int exclude_self, int64_t row_offset, int64_t col_offset, const FastOperands& fo, int64_t* out_idx,
@@ -328,7 +331,7 @@ int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d
     }
     const bool shared = same || slice0 >= 0;
     const int64_t n_pad = (n + 255) / 256 * 256, m_pad = (m + 255) / 256 * 256 + (slice0 >= 0 ? 256 : 0);
-    FastTail ft(n, m, kk, cap, forced_splits);
+    FastTail ft(n, m, kk, cap, forced_splits, dp);
     size_t need = ws_bytes(n, 4) + ws_bytes(m, 4) + ws_bytes((size_t)n_pad * dp, 2) + ws_bytes((size_t)m_pad * dp, 2) +
                   4 * ws_bytes(n_pad, 4) + 4 * ws_bytes(m_pad, 4) + 3 * ws_bytes(4, 4) + ft.bytes();
     Workspace ws;
@@ -506,7 +509,7 @@ int mmf_simtopk_prepared(const void* X, int64_t n, const void* Y, int64_t m, int
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   DeviceGuard guard(device_id);
   if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
-  FastTail ft(n, m, kk, cap, opts ? opts->col_splits : 0);
+  FastTail ft(n, m, kk, cap, opts ? opts->col_splits : 0, scan_bf16_dp(d));
   Workspace ws;
   MMF_TRY(get_workspace(device_id, s, ft.bytes(), &ws));
   ft.carve(ws);

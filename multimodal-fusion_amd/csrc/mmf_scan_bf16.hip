@@ -31,11 +31,7 @@
 
 namespace mmf {
 
-constexpr int B_NT = 512;
-constexpr int B_WAVES = 8;
-constexpr int B_QT = 256;
 constexpr int B_CT = 32;
-constexpr int B_STAGES = 4;   // two PAIRS of tiles: one pair is read while the other is filled
 constexpr int B_CAP = 12;
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -177,20 +173,26 @@ struct ScanB16Args {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), \
                                    (__attribute__((address_space(3))) void*)(lptr), size, 0, 0)
 
-template <int KS, bool F16, bool DBG>
-__global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
+// NW waves per workgroup (32 queries each), TPB tiles per barrier (2 * TPB tile stages in LDS):
+//   d <= 512 : NW = 8 (two waves per SIMD, 256 VGPRs each), TPB = 2
+//   d <= 1024: NW = 4 (one wave per SIMD, the 256 VGPRs of resident query fragments spill over into AGPRs), TPB = 1
+template <int KS, bool F16, bool DBG, int NW, int TPB>
+__global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(ScanB16Args a) {
+  constexpr int NT = 64 * NW;
+  constexpr int QT = 32 * NW;
+  constexpr int STAGES = 2 * TPB;
   constexpr int ROWB = KS * 32;                 // bytes per candidate row in LDS (= DP * 2)
   constexpr int TILEB = B_CT * ROWB;            // bytes per tile
   constexpr int PIECES = TILEB / 1024;          // 1 KiB DMA pieces per tile (= KS)
-  constexpr int PPW = (PIECES + B_WAVES - 1) / B_WAVES;
-  static_assert(PIECES % B_WAVES == 0 || PIECES < B_WAVES, "piece distribution");
+  constexpr int PPW = (PIECES + NW - 1) / NW;
+  static_assert(PIECES % NW == 0, "piece distribution");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  char* tiles = smem;                                                  // [B_STAGES][TILEB]
-  float* cbs = reinterpret_cast<float*>(smem + B_STAGES * TILEB);      // [B_STAGES][64]
+  char* tiles = smem;                                                  // [STAGES][TILEB]
+  float* cbs = reinterpret_cast<float*>(smem + STAGES * TILEB);      // [STAGES][64]
   // Candidate lists (SlotList, mmf_dev.h): approximate keys in LDS, column ids in a global slot block of
   // this workgroup — leaving most of LDS to the tile ring is what buys the fourth stage.
-  float* lkeys = cbs + B_STAGES * 64;                                  // [B_CAP][B_NT]
-  uint32_t* lids = a.lids + (size_t)blockIdx.x * (16 * B_NT);
+  float* lkeys = cbs + STAGES * 64;                                  // [B_CAP][NT]
+  uint32_t* lids = a.lids + (size_t)blockIdx.x * (16 * NT);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
     else { const int g = S >> 3; split = x + 8 * (int)(q % g); rb = q / g; }
   }
   if (rb >= a.row_blocks) return;
-  const int64_t q0 = rb * B_QT;
+  const int64_t q0 = rb * QT;
   int64_t t_begin = (int64_t)split * a.tiles_per_split;
   int64_t t_end = t_begin + a.tiles_per_split;
   if (t_end > a.tiles_total) t_end = a.tiles_total;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
     margin = 2.0f * (e1 + e2) * 1.001f + 1e-30f;
   }
 
-  SlotList<B_CAP, B_NT> list;
+  SlotList<B_CAP, NT> list;
   list.init(lkeys + tid, lids + tid);
   if (!qvalid) list.thr = __builtin_huge_valf();
 
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
   uint32_t src_off[PPW];
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
-    const int p = wave + B_WAVES * i;
+    const int p = wave + NW * i;
     const int off = p * 1024 + lane * 16;
     const int r = off / ROWB;
     const int chunk = (off % ROWB) >> 4;
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
   const char* zc0 = reinterpret_cast<const char*>(a.ZC) + t_begin * (int64_t)TILEB;          // tile 0 of my range
   const char* cb0 = reinterpret_cast<const char*>(a.cb + t_begin * B_CT);
   auto issue_piece = [&](const char* tsrc, int stage, int i) {
-    MMF_GLDS(tsrc + src_off[i], tiles + stage * TILEB + (wave + B_WAVES * i) * 1024, 16);
+    MMF_GLDS(tsrc + src_off[i], tiles + stage * TILEB + (wave + NW * i) * 1024, 16);
   };
   // the 32 biases of a tile: one 4-byte DMA by lanes 0..31 of the wave whose turn it is
   auto issue_bias = [&](const char* bsrc, int stage) {
@@ -283,13 +285,14 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
   };
 
   const int Ti = (int)T;
-  if (Ti > 0) {   // pair 0 = tiles 0, 1 -> stages 0, 1
+  if (Ti > 0) {   // first group of TPB tiles -> stages 0 .. TPB-1
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) issue_piece(zc0, 0, i);
-    if (wave == 0) issue_bias(cb0, 0);
+    for (int u = 0; u < TPB; ++u) {
+      const bool real = u < Ti;
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) issue_piece(Ti > 1 ? zc0 + TILEB : zc0, 1, i);
-    if (wave == 1) issue_bias(Ti > 1 ? cb0 + B_CT * 4 : cb0, 1);
+      for (int i = 0; i < PPW; ++i) issue_piece(real ? zc0 + u * (int64_t)TILEB : zc0, u, i);
+      if (wave == (u & (NW - 1))) issue_bias(real ? cb0 + u * B_CT * 4 : cb0, u);
+    }
   }
   // The two waves that share a SIMD (w and w+4) run in lockstep after every barrier.  Issuing the
   // tile DMA inside the MFMA chain, at different points for the two, lets one wave's VMEM issue sit
@@ -297,10 +300,10 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
   // The chain itself is straight-line code: two copies of the tile body (lower / upper wave group),
   // and the DMA of tile t+2 is unconditional — past the end of the range it re-fetches tile 0 into a
   // stage nobody reads again — so no branch and no per-tile bookkeeping sits between the MFMAs.
-  const bool upper = wave >= 4;
+  const bool upper = wave >= NW / 2;
   constexpr int GRP = KS / PPW;                      // MFMAs between two DMA pieces
-  const char* tsrc = zc0 + 2 * (int64_t)TILEB;       // source of tile t+2
-  const char* bsrc = cb0 + 2 * B_CT * 4;
+  const char* tsrc = zc0 + TPB * (int64_t)TILEB;     // source of the first tile of the NEXT group
+  const char* bsrc = cb0 + TPB * B_CT * 4;
   const uint32_t id_base = (uint32_t)(t_begin * B_CT);
 
   auto tile_body = [&](auto up_tag, const char* tb, const float* cbt, const char* src, int s2) -> f32x16 {
@@ -376,48 +379,49 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
     if (DBG && (a.debug & 8) && lane == 0) atomicAdd(a.dbg + 5, 1ull);   // tiles
   };
 
-  // Main loop: TWO tiles per barrier.  Iteration j reads the pair of stages holding tiles 2j, 2j+1 and
-  // fills the other pair with tiles 2j+2, 2j+3 (DMA pieces issued inside the two MFMA chains), so at the
-  // top of an iteration everything this wave has in flight is exactly what the iteration needs:
+  // Main loop: TPB tiles per barrier.  Iteration j reads the group of stages holding tiles j*TPB ..
+  // and fills the other group with the next TPB tiles (DMA pieces issued inside the MFMA chains), so at
+  // the top of an iteration everything this wave has in flight is exactly what the iteration needs:
   // vmcnt(0), barrier.  Past the end of the range the DMA re-fetches tile 0 into a stage nobody reads.
   unsigned long long tw = 0, tf = 0, tc = 0, t0s = 0, t1s = 0, t2s = 0, t3s = 0;
   const bool stamps = DBG && (a.debug & 16) != 0;
   f32x16 acc_prev;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc_prev[r] = kNegInf;      // "tile -1": nothing can hit
-  const int nIter = (Ti + 1) >> 1;
+  const int nIter = (Ti + TPB - 1) / TPB;
   for (int j = 0; j < nIter; ++j) {
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) alone (expcnt 7, lgkmcnt 15 = no wait)
     if (stamps) t0s = __builtin_amdgcn_s_memtime();
     asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // this pair is visible to all; everyone is done READING the other pair
+    __builtin_amdgcn_s_barrier();   // this group is visible to all; everyone is done READING the other group
     asm volatile("" ::: "memory");
     if (stamps) t1s = __builtin_amdgcn_s_memtime();
 
-    const int t0 = 2 * j, t1 = t0 + 1;
-    filter(acc_prev, t0 - 1);
+    filter(acc_prev, j * TPB - 1);  // behind the barrier: only this wave waits for its own list code
     if (stamps) t2s = __builtin_amdgcn_s_memtime();
 
-    const int sa = (j & 1) * 2, sb = sa + 1, na = 2 - sa, nb = na + 1;
-    const bool more0 = (t0 + 2 < Ti), more1 = (t1 + 2 < Ti);
-    const char* src0 = more0 ? tsrc : zc0;
-    const char* src1 = more1 ? tsrc + TILEB : zc0;
-
-    f32x16 acc0;
-    if (upper) acc0 = tile_body(std::true_type{}, tiles + sa * TILEB, cbs + sa * 64, src0, na);
-    else acc0 = tile_body(std::false_type{}, tiles + sa * TILEB, cbs + sa * 64, src0, na);
-    if (wave == ((t0 + 2) & 7)) issue_bias(more0 ? bsrc : cb0, na);
-    filter(acc0, t0);               // no barrier nearby: only this wave waits for its own list code
-
-    if (upper) acc_prev = tile_body(std::true_type{}, tiles + sb * TILEB, cbs + sb * 64, src1, nb);
-    else acc_prev = tile_body(std::false_type{}, tiles + sb * TILEB, cbs + sb * 64, src1, nb);
-    if (wave == ((t1 + 2) & 7)) issue_bias(more1 ? bsrc + B_CT * 4 : cb0, nb);
-    if (t1 >= Ti) {                 // odd range: the second tile of the last pair is a dummy
+    const int sg = (j & 1) * TPB, ng = TPB - sg;      // stage group read / filled by this iteration
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc_prev[r] = kNegInf;
+    for (int u = 0; u < TPB; ++u) {
+      const int t = j * TPB + u;
+      const bool more = (t + TPB < Ti);
+      const char* src = more ? tsrc + u * (int64_t)TILEB : zc0;
+      f32x16 acc;
+      if (upper) acc = tile_body(std::true_type{}, tiles + (sg + u) * TILEB, cbs + (sg + u) * 64, src, ng + u);
+      else acc = tile_body(std::false_type{}, tiles + (sg + u) * TILEB, cbs + (sg + u) * 64, src, ng + u);
+      if (wave == ((t + TPB) & (NW - 1))) issue_bias(more ? bsrc + u * B_CT * 4 : cb0, ng + u);
+      if (u < TPB - 1) {
+        filter(acc, t);             // mid-iteration, no barrier nearby
+      } else {
+        if (t >= Ti) {              // ragged range: the last tile of the last group is a dummy
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = kNegInf;
+        }
+        acc_prev = acc;
+      }
     }
-    tsrc += 2 * TILEB;
-    bsrc += 2 * B_CT * 4;
+    tsrc += TPB * (int64_t)TILEB;
+    bsrc += TPB * B_CT * 4;
     if (stamps) {
       asm volatile("" :: "v"(acc_prev[0]));          // the chain's result must exist before the stamp
       t3s = __builtin_amdgcn_s_memtime();
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(B_NT, 2) void scan_b16_kernel(ScanB16Args a) {
   if (stamps && lane == 0) {
     atomicAdd(a.dbg + 0, tw); atomicAdd(a.dbg + 1, tf); atomicAdd(a.dbg + 2, tc); atomicAdd(a.dbg + 3, (unsigned long long)Ti);
   }
-  if (Ti > 0) filter(acc_prev, 2 * nIter - 1);
+  if (Ti > 0) filter(acc_prev, nIter * TPB - 1);
   __builtin_amdgcn_s_waitcnt(0x0F70);   // the dummy tiles still in flight
 
   list.compact(a.kk, margin);
@@ -447,8 +451,10 @@ static int pad_dp(int64_t d) {
   if (d <= 128) return 128;
   if (d <= 256) return 256;
   if (d <= 512) return 512;
+  if (d <= 1024) return 1024;
   return 0;
 }
+static int waves_for_dp(int dp) { return dp <= 512 ? 8 : 4; }   // workgroup shape of the kernel variant
 
 int scan_bf16_supported(int64_t d, int kk, int dtype) {
   (void)dtype;
@@ -469,12 +475,15 @@ int launch_prep_half(const void* X, int64_t n, int64_t d, int dtype, int metric,
   return MMF_OK;
 }
 
-static size_t scan_b16_lds(int ks) {
-  return (size_t)B_STAGES * (B_CT * ks * 32) + (size_t)B_STAGES * 64 * 4 + (size_t)B_CAP * B_NT * 4;
+static size_t scan_b16_lds(int ks, int nw, int tpb) {
+  return (size_t)(2 * tpb) * (B_CT * ks * 32) + (size_t)(2 * tpb) * 64 * 4 + (size_t)B_CAP * (64 * nw) * 4;
 }
 
-static int64_t scan_b16_grid(int64_t n_rows, int col_splits) {
-  const int64_t row_blocks = (n_rows + B_QT - 1) / B_QT;
+int scan_b16_queries_per_block(int dp) { return 32 * waves_for_dp(dp); }
+
+static int64_t scan_b16_grid(int64_t n_rows, int col_splits, int dp) {
+  const int qt = scan_b16_queries_per_block(dp);
+  const int64_t row_blocks = (n_rows + qt - 1) / qt;
   if (col_splits <= 8) {
     const int per = 8 / col_splits;                       // row blocks per group of 8 block ids
     return ((row_blocks + per - 1) / per) * 8;
@@ -482,26 +491,26 @@ static int64_t scan_b16_grid(int64_t n_rows, int col_splits) {
   return row_blocks * col_splits;                         // col_splits multiple of 8: exact
 }
 
-// bytes of the global id-slot scratch ([grid][16][B_NT] u32) a launch needs
-size_t scan_b16_scratch_bytes(int64_t n_rows, int col_splits) {
-  return (size_t)scan_b16_grid(n_rows, col_splits) * 16 * B_NT * 4 + 256;
+// bytes of the global id-slot scratch ([grid][16][threads] u32) a launch needs
+size_t scan_b16_scratch_bytes(int64_t n_rows, int col_splits, int dp) {
+  return (size_t)scan_b16_grid(n_rows, col_splits, dp) * 16 * (64 * waves_for_dp(dp)) * 4 + 256;
 }
 
-template <int KS>
+template <int KS, int NW, int TPB>
 static int launch_b16_t(const ScanB16Args& a, bool f16, int64_t grid, hipStream_t s) {
-  const size_t lds = scan_b16_lds(KS);
+  const size_t lds = scan_b16_lds(KS, NW, TPB);
   auto go = [&](auto kern) -> int {
     MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(B_NT), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NW), lds, s, a);
     MMF_LAUNCH_CHECK();
     return MMF_OK;
   };
   if (a.debug != 0) {   // instrumented build of the same kernel (MMF_SCAN_DEBUG)
-    if (f16) return go(scan_b16_kernel<KS, true, true>);
-    return go(scan_b16_kernel<KS, false, true>);
+    if (f16) return go(scan_b16_kernel<KS, true, true, NW, TPB>);
+    return go(scan_b16_kernel<KS, false, true, NW, TPB>);
   }
-  if (f16) return go(scan_b16_kernel<KS, true, false>);
-  return go(scan_b16_kernel<KS, false, false>);
+  if (f16) return go(scan_b16_kernel<KS, true, false, NW, TPB>);
+  return go(scan_b16_kernel<KS, false, false, NW, TPB>);
 }
 
 // col_splits must be a power of two.  Lists are indexed by query position, cap = B_CAP.
@@ -513,7 +522,7 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
   a.ZQ = ZQ; a.ZC = ZC; a.cb = cb; a.q_zn = q_zn; a.q_rn = q_rn; a.q_un = q_un; a.maxima = maxima;
   a.n_rows = n_rows; a.m = m; a.tiles_total = m_pad / B_CT;
   a.tiles_per_split = (a.tiles_total + col_splits - 1) / col_splits;
-  a.row_blocks = (n_rows + B_QT - 1) / B_QT;
+  a.row_blocks = (n_rows + scan_b16_queries_per_block(dp) - 1) / scan_b16_queries_per_block(dp);
   a.col_splits = col_splits; a.kk = kk; a.metric = metric; a.d = (int)d;
   {
     const char* dbg = getenv("MMF_SCAN_DEBUG");
@@ -527,14 +536,15 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
     }
   }
   a.cand_cnt = L.cnt; a.cand_ids = L.ids; a.overflow = L.overflow;
-  const int64_t grid = scan_b16_grid(n_rows, col_splits);
+  const int64_t grid = scan_b16_grid(n_rows, col_splits, dp);
   a.lids = reinterpret_cast<uint32_t*>(scratch);
   if (grid_out) *grid_out = (int)grid;
   int rc = MMF_E_INTERNAL;
   switch (dp) {
-    case 128: rc = launch_b16_t<8>(a, f16, grid, s); break;
-    case 256: rc = launch_b16_t<16>(a, f16, grid, s); break;
-    case 512: rc = launch_b16_t<32>(a, f16, grid, s); break;
+    case 128: rc = launch_b16_t<8, 8, 2>(a, f16, grid, s); break;
+    case 256: rc = launch_b16_t<16, 8, 2>(a, f16, grid, s); break;
+    case 512: rc = launch_b16_t<32, 8, 2>(a, f16, grid, s); break;
+    case 1024: rc = launch_b16_t<64, 4, 1>(a, f16, grid, s); break;
     default: set_error("scan_b16: unsupported padded dim %d", dp);
   }
   if (rc == MMF_OK && (a.debug & 16)) {

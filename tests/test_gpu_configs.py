@@ -125,9 +125,19 @@ def test_c4_row_sharded_equals_unsharded(mmf):
 def test_c5_fp16_features_d1024(mmf):
     X = make(3000, 1024, 7).half()
     ridx, rval = oracle.simtopk(X.float().cpu().numpy(), metric="cosine", k=5)
-    idx, val, st = mmf.simtopk(X, metric="cosine", k=5, return_stats=True)      # AUTO: d > 512 -> exact f32-MFMA scan
-    assert st["precision_used"] == 1
-    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(val.cpu().numpy(), rval)
+    for prec, used in (("auto", 2), ("exact", 1)):    # d = 1024 runs on the 4-wave variant of the 16-bit scan
+        idx, val, st = mmf.simtopk(X, metric="cosine", k=5, precision=prec, return_stats=True)
+        assert st["precision_used"] == used
+        assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(val.cpu().numpy(), rval), prec
+    Xb = make(40000, 1024, 9).half()                                           # bigger, through properties + oracle blocks
+    idx, val, st = mmf.simtopk(Xb, metric="cosine", k=5, return_stats=True)
+    assert st["precision_used"] == 2
+    check_properties(idx, val, 40000, 40000, 0, True)
+    check_against_oracle_blocks(Xb.float(), None, idx, val, 5, True, blocks=2, rows=8)
+    Xc = make(5000, 700, 10)                                                    # ragged d between the padded sizes
+    ri, rv = oracle.simtopk(Xc.cpu().numpy(), metric="neg_sq_l2", k=4)
+    idx, val, st = mmf.simtopk(Xc, metric="neg_sq_l2", k=4, return_stats=True)
+    assert st["precision_used"] == 2 and np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(val.cpu().numpy(), rv)
     Xh = make(20000, 512, 8).half()                                            # fp16 features on the 16-bit scan
     idx, val, st = mmf.simtopk(Xh, metric="cosine", k=5, return_stats=True)
     assert st["precision_used"] == 2
