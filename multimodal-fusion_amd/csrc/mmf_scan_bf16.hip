@@ -32,7 +32,8 @@
 namespace mmf {
 
 constexpr int B_CT = 32;
-constexpr int B_CAP = 12;
+constexpr int B_CAP = 12;       // list entries per lane for k + self <= 8
+constexpr int B_CAP_BIG = 16;   // ... for k + self <= 12 (costs the fourth tile stage: TPB = 1)
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
@@ -176,7 +177,7 @@ struct ScanB16Args {
 // NW waves per workgroup (32 queries each), TPB tiles per barrier (2 * TPB tile stages in LDS):
 //   d <= 512 : NW = 8 (two waves per SIMD, 256 VGPRs each), TPB = 2
 //   d <= 1024: NW = 4 (one wave per SIMD, the 256 VGPRs of resident query fragments spill over into AGPRs), TPB = 1
-template <int KS, bool F16, bool DBG, int NW, int TPB>
+template <int KS, bool F16, bool DBG, int NW, int TPB, int CAP>
 __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(ScanB16Args a) {
   constexpr int NT = 64 * NW;
   constexpr int QT = 32 * NW;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(Sc
   float* cbs = reinterpret_cast<float*>(smem + STAGES * TILEB);      // [STAGES][64]
   // Candidate lists (SlotList, mmf_dev.h): approximate keys in LDS, column ids in a global slot block of
   // this workgroup — leaving most of LDS to the tile ring is what buys the fourth stage.
-  float* lkeys = cbs + STAGES * 64;                                  // [B_CAP][NT]
+  float* lkeys = cbs + STAGES * 64;                                  // [CAP][NT]
   uint32_t* lids = a.lids + (size_t)blockIdx.x * (16 * NT);
 
   const int tid = threadIdx.x;
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(Sc
     margin = 2.0f * (e1 + e2) * 1.001f + 1e-30f;
   }
 
-  SlotList<B_CAP, NT> list;
+  SlotList<CAP, NT> list;
   list.init(lkeys + tid, lids + tid);
   if (!qvalid) list.thr = __builtin_huge_valf();
 
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(Sc
       // robust (never dropping) path while thresholds are still forming: first 32 tiles of the range
       const bool cold = (tt < 32) || __any(list.thr == -kFltMax);
       if (DBG && (a.debug & 8)) {
-        const bool willc = __any(list.cnt >= B_CAP - 1);
+        const bool willc = __any(list.cnt >= CAP - 1);
         int nh = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) nh += (acc[r] >= list.thr) ? 1 : 0;
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(Sc
   if (qvalid) {
     const int64_t lbase = qpos * (2 * a.col_splits) + 2 * split + half;
     a.cand_cnt[lbase] = (uint32_t)list.cnt;
-    for (int e = 0; e < list.cnt; ++e) a.cand_ids[lbase * B_CAP + e] = list.id_of(e);
+    for (int e = 0; e < list.cnt; ++e) a.cand_ids[lbase * CAP + e] = list.id_of(e);
     if (list.overflow) atomicOr(a.overflow + qpos, 1u);
   }
 }
@@ -458,10 +459,10 @@ static int waves_for_dp(int dp) { return dp <= 512 ? 8 : 4; }   // workgroup sha
 
 int scan_bf16_supported(int64_t d, int kk, int dtype) {
   (void)dtype;
-  return (pad_dp(d) != 0 && kk <= B_CAP - 4) ? 1 : 0;
+  return (pad_dp(d) != 0 && kk <= B_CAP_BIG - 4) ? 1 : 0;
 }
 
-int scan_bf16_cap() { return B_CAP; }
+int scan_bf16_cap(int kk) { return kk <= B_CAP - 4 ? B_CAP : B_CAP_BIG; }
 int scan_bf16_dp(int64_t d) { return pad_dp(d); }
 
 int launch_prep_half(const void* X, int64_t n, int64_t d, int dtype, int metric, const float* scal,
@@ -475,8 +476,8 @@ int launch_prep_half(const void* X, int64_t n, int64_t d, int dtype, int metric,
   return MMF_OK;
 }
 
-static size_t scan_b16_lds(int ks, int nw, int tpb) {
-  return (size_t)(2 * tpb) * (B_CT * ks * 32) + (size_t)(2 * tpb) * 64 * 4 + (size_t)B_CAP * (64 * nw) * 4;
+static size_t scan_b16_lds(int ks, int nw, int tpb, int cap) {
+  return (size_t)(2 * tpb) * (B_CT * ks * 32) + (size_t)(2 * tpb) * 64 * 4 + (size_t)cap * (64 * nw) * 4;
 }
 
 int scan_b16_queries_per_block(int dp) { return 32 * waves_for_dp(dp); }
@@ -496,9 +497,9 @@ size_t scan_b16_scratch_bytes(int64_t n_rows, int col_splits, int dp) {
   return (size_t)scan_b16_grid(n_rows, col_splits, dp) * 16 * (64 * waves_for_dp(dp)) * 4 + 256;
 }
 
-template <int KS, int NW, int TPB>
+template <int KS, int NW, int TPB, int CAP>
 static int launch_b16_t(const ScanB16Args& a, bool f16, int64_t grid, hipStream_t s) {
-  const size_t lds = scan_b16_lds(KS, NW, TPB);
+  const size_t lds = scan_b16_lds(KS, NW, TPB, CAP);
   auto go = [&](auto kern) -> int {
     MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NW), lds, s, a);
@@ -506,11 +507,11 @@ static int launch_b16_t(const ScanB16Args& a, bool f16, int64_t grid, hipStream_
     return MMF_OK;
   };
   if (a.debug != 0) {   // instrumented build of the same kernel (MMF_SCAN_DEBUG)
-    if (f16) return go(scan_b16_kernel<KS, true, true, NW, TPB>);
-    return go(scan_b16_kernel<KS, false, true, NW, TPB>);
+    if (f16) return go(scan_b16_kernel<KS, true, true, NW, TPB, CAP>);
+    return go(scan_b16_kernel<KS, false, true, NW, TPB, CAP>);
   }
-  if (f16) return go(scan_b16_kernel<KS, true, false, NW, TPB>);
-  return go(scan_b16_kernel<KS, false, false, NW, TPB>);
+  if (f16) return go(scan_b16_kernel<KS, true, false, NW, TPB, CAP>);
+  return go(scan_b16_kernel<KS, false, false, NW, TPB, CAP>);
 }
 
 // col_splits must be a power of two.  Lists are indexed by query position, cap = B_CAP.
@@ -540,11 +541,12 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
   a.lids = reinterpret_cast<uint32_t*>(scratch);
   if (grid_out) *grid_out = (int)grid;
   int rc = MMF_E_INTERNAL;
+  const bool big = (L.cap == B_CAP_BIG);   // k + self in 9..12: 16-entry lists, one tile per barrier
   switch (dp) {
-    case 128: rc = launch_b16_t<8, 8, 2>(a, f16, grid, s); break;
-    case 256: rc = launch_b16_t<16, 8, 2>(a, f16, grid, s); break;
-    case 512: rc = launch_b16_t<32, 8, 2>(a, f16, grid, s); break;
-    case 1024: rc = launch_b16_t<64, 4, 1>(a, f16, grid, s); break;
+    case 128: rc = big ? launch_b16_t<8, 8, 1, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<8, 8, 2, B_CAP>(a, f16, grid, s); break;
+    case 256: rc = big ? launch_b16_t<16, 8, 1, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<16, 8, 2, B_CAP>(a, f16, grid, s); break;
+    case 512: rc = big ? launch_b16_t<32, 8, 1, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<32, 8, 2, B_CAP>(a, f16, grid, s); break;
+    case 1024: rc = big ? launch_b16_t<64, 4, 1, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<64, 4, 1, B_CAP>(a, f16, grid, s); break;
     default: set_error("scan_b16: unsupported padded dim %d", dp);
   }
   if (rc == MMF_OK && (a.debug & 16)) {

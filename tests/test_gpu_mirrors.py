@@ -77,7 +77,7 @@ def test_build_weighted_hypergraph_errors(bh):
         bh.build_weighted_hypergraph(torch.randn(4, 8), torch.rand(4, 2))
     with pytest.raises(ValueError, match="greater than 1"):
         bh.build_weighted_hypergraph(torch.randn(1, 8), torch.rand(1, 2), 1.0, 1.0, 0.5)
-    ei, ew = bh.build_weighted_hypergraph(torch.randn(6, 8), torch.rand(6, 2), 1.0, 1.0, 1e9)   # nothing survives
+    ei, ew = bh.build_weighted_hypergraph(torch.randn(6, 8), torch.rand(6, 2), 1.0, 1.0, float("inf"))   # nothing survives
     assert ei.shape == (2, 0) and ew.shape == (0,) and ei.dtype == torch.int64
 
 

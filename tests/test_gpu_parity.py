@@ -74,7 +74,7 @@ def test_simtopk_self_exact(mmf, metric, n, d, k):
 # the bf16 MFMA scan + exact re-rank must give the SAME bits as the exact scan and the oracle
 @pytest.mark.parametrize("metric", ["dot", "cosine", "neg_sq_l2", "rbf"])
 @pytest.mark.parametrize("n,d,k", [(2, 4, 1), (33, 3, 5), (300, 32, 5), (1000, 128, 7), (257, 100, 7), (2049, 512, 5),
-                                   (5000, 256, 5), (777, 500, 3)])
+                                   (5000, 256, 5), (777, 500, 3), (3000, 128, 11), (1500, 512, 9), (900, 1000, 10)])
 def test_simtopk_self_fast(mmf, metric, n, d, k):
     X = unit_rows(n, d, 10 + n).numpy() if d > 3 else rnd(n, d, 5)
     check_topk(mmf, X, None, metric, k, lam=1.0, precision="fast")
