@@ -24,7 +24,26 @@ from ._common import compute_device, result_device_like_preprocess, to_gpu
 from .similarity_kernel import compute_combined_similarity
 
 
-def _kmeans_labels(x: np.ndarray, n_clusters: int) -> np.ndarray:
+KMEANS_BACKEND = "sklearn"     # "sklearn": the reference's own call on the host (labels identical to the reference)
+                               # "device" : multimodal-fusion_amd/kmeans.py (same objective, different seeding stream)
+
+
+def set_kmeans_backend(name: str) -> None:
+    global KMEANS_BACKEND
+    if name not in ("sklearn", "device"):
+        raise ValueError("kmeans backend must be 'sklearn' or 'device'")
+    KMEANS_BACKEND = name
+
+
+def _kmeans_labels(x, n_clusters: int) -> np.ndarray:
+    if KMEANS_BACKEND == "device":
+        from ..kmeans import kmeans_fit_predict
+        xt = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.asarray(x))
+        if not xt.is_cuda:
+            xt = xt.to(compute_device())
+        return kmeans_fit_predict(xt, n_clusters, n_init=10, seed=42)[0].cpu().numpy()
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
     # the reference's exact call (preprocess_hypergraph.py:150-151, 299-300, 391-392)
     try:
         from sklearn.cluster import KMeans

@@ -1,0 +1,56 @@
+"""Device KMeans against scikit-learn's KMeans(random_state=42, n_init=10), the call
+the reference makes.  Labels cannot match bit for bit (different seeding stream); the objective must."""
+from importlib import import_module
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_kmeans_separable_blobs_same_partition():
+    import multimodal_fusion_amd  # noqa: F401
+    km = import_module("multimodal_fusion_amd.kmeans")
+    from sklearn.cluster import KMeans
+    from sklearn.metrics import adjusted_rand_score
+    rng = np.random.RandomState(0)
+    centers = rng.randn(8, 32).astype(np.float32) * 6.0
+    X = np.concatenate([c + rng.randn(300, 32).astype(np.float32) for c in centers], 0)
+    ref = KMeans(n_clusters=8, random_state=42, n_init=10).fit(X)
+    labels, C, inertia = km.kmeans_fit_predict(torch.from_numpy(X).cuda(), 8)
+    assert adjusted_rand_score(ref.labels_, labels.cpu().numpy()) == 1.0
+    assert abs(inertia - ref.inertia_) <= 1e-4 * ref.inertia_
+    assert labels.dtype == torch.int64 and C.shape == (8, 32)
+
+
+def test_kmeans_unstructured_data_objective():
+    import multimodal_fusion_amd  # noqa: F401
+    km = import_module("multimodal_fusion_amd.kmeans")
+    from sklearn.cluster import KMeans
+    X = np.random.RandomState(1).randn(4000, 64).astype(np.float32)
+    ref = KMeans(n_clusters=10, random_state=42, n_init=10).fit(X)
+    labels, C, inertia = km.kmeans_fit_predict(torch.from_numpy(X).cuda(), 10)
+    assert inertia <= 1.02 * ref.inertia_                         # as good a local optimum, within 2 %
+    # the reported inertia is the objective of the returned partition
+    d2 = ((X - C.cpu().numpy()[labels.cpu().numpy()]) ** 2).sum()
+    assert abs(d2 - inertia) <= 1e-3 * inertia
+    assert int(torch.bincount(labels, minlength=10).min()) > 0
+    with pytest.raises(ValueError):
+        km.kmeans_fit_predict(torch.from_numpy(X[:5]).cuda(), 6)
+
+
+def test_mirror_with_device_kmeans_backend():
+    import multimodal_fusion_amd  # noqa: F401
+    pp = import_module("multimodal_fusion_amd.build_hypergraph.preprocess_hypergraph")
+    rng = np.random.RandomState(2)
+    centers = rng.randn(4, 16).astype(np.float32) * 5.0
+    X = torch.from_numpy(np.concatenate([c + rng.randn(50, 16).astype(np.float32) for c in centers], 0))
+    try:
+        ei_s, ew_s, st_s = pp.build_hypergraph_knn_kmeans(X[:120], X[120:], None, 5, 4)
+        pp.set_kmeans_backend("device")
+        ei_d, ew_d, st_d = pp.build_hypergraph_knn_kmeans(X[:120], X[120:], None, 5, 4)
+    finally:
+        pp.set_kmeans_backend("sklearn")
+    # separable blobs: both backends find the same 4 cliques, hence the same edge set and weights
+    assert torch.equal(ei_s, ei_d) and torch.equal(ew_s, ew_d) and st_s == st_d
