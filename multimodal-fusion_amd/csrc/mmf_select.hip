@@ -24,6 +24,7 @@ struct SelectArgs {
   const uint32_t* cand_cnt; const uint32_t* cand_ids; const uint32_t* overflow; int lists; int cap;
   int64_t* out_idx; float* out_val;
   int32_t* fail_rows; uint32_t* fail_count; uint32_t* cand_total;
+  int maxc;   // staged kernel: candidate slots per wave in dynamic LDS
 };
 
 template <bool VEC4>
@@ -144,10 +145,167 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_kernel(SelectArgs a) {
   }
 }
 
+// f32, d % 4 == 0: the same selection with the candidate rows staged through LDS.  Per query the wave
+// walks its candidates in groups of 16 and k in chunks of 128: every global read is a coalesced
+// 512-byte row segment (two candidates per wave instruction, eight instructions in flight), and the
+// canonical k-ordered chains run out of LDS (row stride 132 floats: conflict-free ds_read_b128),
+// one lane per candidate.
+constexpr int SG = 16;
+constexpr int SC = 128;
+constexpr int SLD = SC + 4;
+
+template <int METRIC>
+__global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArgs a) {
+  // dynamic LDS: per wave [maxc] keys + [maxc] ids (maxc = lists * cap rounded up to 64), then the tiles
+  extern __shared__ __attribute__((aligned(16))) char sel_smem[];
+  const int maxc = a.maxc;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float (*ytile)[SG][SLD] = reinterpret_cast<float (*)[SG][SLD]>(sel_smem);
+  float (*xtile)[SC] = reinterpret_cast<float (*)[SC]>(sel_smem + sizeof(float) * SEL_WAVES * SG * SLD);
+  float* skey_base = reinterpret_cast<float*>(sel_smem + sizeof(float) * SEL_WAVES * (SG * SLD + SC));
+  uint32_t* sid_base = reinterpret_cast<uint32_t*>(skey_base + SEL_WAVES * maxc);
+  const int64_t pos = (int64_t)blockIdx.x * SEL_WAVES + wave;
+  if (pos >= a.n_rows) return;
+  const int64_t row = a.row_ids ? (int64_t)a.row_ids[pos] : pos;
+  float* key = skey_base + wave * maxc;
+  uint32_t* id = sid_base + wave * maxc;
+  const float* X = reinterpret_cast<const float*>(a.X);
+  const float* Y = reinterpret_cast<const float*>(a.Y);
+
+  bool failed = a.overflow[pos] != 0;
+  const bool was_overflow = failed;
+  int total = 0;
+  if (!failed) {
+    for (int l = 0; l < a.lists; ++l) {
+      const uint32_t cn = a.cand_cnt[pos * a.lists + l];
+      if (total + (int)cn > maxc) { failed = true; break; }
+      for (uint32_t e = lane; e < cn; e += 64) id[total + e] = a.cand_ids[(pos * a.lists + l) * a.cap + e];
+      total += (int)cn;
+    }
+  }
+  const int64_t grow = a.row_offset + row;
+  int valid = 0;
+  if (!failed) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    const float ri = a.rx[row];
+    const int hl = lane >> 5, ll = lane & 31;
+    for (int g0 = 0; g0 < total; g0 += SG) {
+      const int ng = (total - g0 < SG) ? (total - g0) : SG;
+      // this lane's candidate (chain phase) and its admissibility
+      uint32_t myj = kNoIdx;
+      bool ok = false;
+      if (lane < ng) {
+        myj = id[g0 + lane];
+        ok = ((int64_t)myj < a.m) && !(a.exclude_self && (a.col_offset + (int64_t)myj == grow));
+      }
+      float acc = 0.0f;
+      // loads of chunk c+1 are issued before the chains of chunk c run (registers), written to LDS after
+      f32x4 xv, yv[SG / 2];
+      auto gload = [&](int64_t k0) {
+        const int kc = (a.d - k0 < SC) ? (int)(a.d - k0) : SC;
+        xv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (hl == 0 && 4 * ll < kc) xv = *reinterpret_cast<const f32x4*>(X + row * a.d + k0 + 4 * ll);
+#pragma unroll
+        for (int p = 0; p < SG / 2; ++p) {
+          const int cnd = 2 * p + hl;
+          yv[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (cnd < ng && 4 * ll < kc) {
+            uint32_t j = id[g0 + cnd];
+            if ((int64_t)j >= a.m) j = 0;
+            yv[p] = *reinterpret_cast<const f32x4*>(Y + (int64_t)j * a.d + k0 + 4 * ll);
+          }
+        }
+      };
+      gload(0);
+      for (int64_t k0 = 0; k0 < a.d; k0 += SC) {
+        const int kc = (a.d - k0 < SC) ? (int)(a.d - k0) : SC;
+        if (hl == 0) *reinterpret_cast<f32x4*>(&xtile[wave][4 * ll]) = xv;
+#pragma unroll
+        for (int p = 0; p < SG / 2; ++p) *reinterpret_cast<f32x4*>(&ytile[wave][2 * p + hl][4 * ll]) = yv[p];
+        if (k0 + SC < a.d) gload(k0 + SC);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        if (lane < ng) {
+          for (int kk = 0; kk < kc; kk += 4) {
+            const f32x4 x4 = *reinterpret_cast<const f32x4*>(&xtile[wave][kk]);
+            const f32x4 y4 = *reinterpret_cast<const f32x4*>(&ytile[wave][lane][kk]);
+            acc = __builtin_fmaf(x4[0], y4[0], acc);
+            acc = __builtin_fmaf(x4[1], y4[1], acc);
+            acc = __builtin_fmaf(x4[2], y4[2], acc);
+            acc = __builtin_fmaf(x4[3], y4[3], acc);
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+      }
+      if (lane < ng) {
+        float kx = kNegInf;
+        if (ok) {
+          kx = key_from_dot<METRIC>(acc, ri, a.cy[myj], a.neg_lambda);
+          if (kx != kx) kx = kNegInf;
+          ++valid;
+        } else {
+          id[g0 + lane] = kNoIdx;
+        }
+        key[g0 + lane] = kx;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) valid += __shfl_xor(valid, o);
+    if (valid < a.k) failed = true;
+  }
+  if (failed) {
+    if (lane == 0) {
+      const uint32_t slot = atomicAdd(a.fail_count, 1u);
+      a.fail_rows[slot] = (int32_t)pos;
+      atomicAdd(a.fail_count + (was_overflow ? 1 : 2), 1u);
+    }
+    return;
+  }
+  if (a.cand_total && lane == 0) atomicAdd(a.cand_total + (blockIdx.x & 255), (uint32_t)total);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  for (int t = 0; t < a.k; ++t) {
+    float bk = kNegInf;
+    uint32_t bi = kNoIdx;
+    int be = -1;
+    for (int e = lane; e < total; e += 64) {
+      const uint32_t ie = id[e];
+      if (ie != kNoIdx && (be < 0 || better(key[e], ie, bk, bi))) { bk = key[e]; bi = ie; be = e; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ok2 = __shfl_xor(bk, o);
+      const uint32_t oi = (uint32_t)__shfl_xor((int)bi, o);
+      const int oe = __shfl_xor(be, o);
+      const bool take = (oe >= 0) && (be < 0 || better(ok2, oi, bk, bi));
+      if (take) { bk = ok2; bi = oi; be = oe; }
+    }
+    if (be >= 0 && (be & 63) == lane) id[be] = kNoIdx;
+    if (lane == 0) {
+      a.out_idx[row * a.k + t] = a.col_offset + (int64_t)bi;
+      a.out_val[row * a.k + t] = val_from_key<METRIC>(bk);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <int METRIC>
 static int launch_select_m(const SelectArgs& a, bool vec4, hipStream_t s) {
   const int64_t grid = (a.n_rows + SEL_WAVES - 1) / SEL_WAVES;
-  if (vec4) hipLaunchKernelGGL((select_kernel<METRIC, true>), dim3((unsigned)grid), dim3(64 * SEL_WAVES), 0, s, a);
+  if (vec4 && a.d >= 64) {
+    SelectArgs b = a;
+    b.maxc = ((a.lists * a.cap + 63) / 64) * 64;
+    const size_t lds = sizeof(float) * SEL_WAVES * (SG * SLD + SC) + (size_t)SEL_WAVES * b.maxc * 8;
+    auto kern = select_staged_kernel<METRIC>;
+    MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * SEL_WAVES), lds, s, b);
+  } else if (vec4) hipLaunchKernelGGL((select_kernel<METRIC, true>), dim3((unsigned)grid), dim3(64 * SEL_WAVES), 0, s, a);
   else hipLaunchKernelGGL((select_kernel<METRIC, false>), dim3((unsigned)grid), dim3(64 * SEL_WAVES), 0, s, a);
   MMF_LAUNCH_CHECK();
   return MMF_OK;
