@@ -178,3 +178,22 @@ def test_phase_api_equals_single_call(mmf, metric):
         i, v, st = ops.simtopk_prepared(X[lo:hi], X, q, dict(Z=Z, **side), m_pad, max4, metric=metric, k=k,
                                         exclude_self=True, row_offset=lo, wait_event=ev, return_stats=True)
         assert torch.equal(i, full_i[lo:hi]) and torch.equal(v, full_v[lo:hi]), (metric, r)
+
+
+def test_c5_full_size_shard_of_eight(mmf):
+    """BASELINE config 5 at full size: N = 1048576, d = 1024, fp16 features.  One GPU runs what rank 5 of 8
+    would (131072 local rows against all 1M columns, 2.8e14 flop) and the oracle checks sampled rows."""
+    N, d, P, r = 1048576, 1024, 8, 5
+    X = torch.empty((N, d), dtype=torch.float16, device="cuda")
+    for b in range(0, N, 65536):
+        g = torch.Generator(device="cuda").manual_seed(5000 + b)
+        blk = torch.randn((65536, d), generator=g, device="cuda", dtype=torch.float32)
+        X[b:b + 65536] = (blk / blk.norm(dim=1, keepdim=True)).half()
+    lo, hi = r * (N // P), (r + 1) * (N // P)
+    idx, val, st = mmf.simtopk(X[lo:hi], X, metric="cosine", k=5, exclude_self=True, row_offset=lo, return_stats=True)
+    assert st["precision_used"] == 2 and st["fallback_rows"] < 64
+    check_properties(idx, val, hi - lo, N, lo, True)
+    Xh = X.float().cpu().numpy()
+    for off in (0, 70000, hi - lo - 8):
+        ri, rv = oracle.simtopk(Xh[lo + off:lo + off + 8], Xh, metric="cosine", k=5, exclude_self=True, row_offset=lo + off)
+        assert np.array_equal(idx[off:off + 8].cpu().numpy(), ri) and np.array_equal(val[off:off + 8].cpu().numpy(), rv)
