@@ -65,7 +65,8 @@ __global__ __launch_bounds__(F_NT) void scan_f32_kernel(ScanF32Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* Qs = reinterpret_cast<float*>(smem);   // [2][F_QT][F_LD]
   float* Cs = Qs + 2 * F_QT * F_LD;             // [2][F_CT][F_LD]
-  float* lkeys = Cs + 2 * F_CT * F_LD;          // [CAP][F_NT]
+  float* cys = Cs + 2 * F_CT * F_LD;            // [2][F_CT] per-candidate scalars of the tile being accumulated
+  float* lkeys = cys + 2 * F_CT;                // [CAP][F_NT]
   uint32_t* lids = reinterpret_cast<uint32_t*>(lkeys + CAP * F_NT);
 
   const int tid = threadIdx.x;
@@ -111,9 +112,15 @@ __global__ __launch_bounds__(F_NT) void scan_f32_kernel(ScanF32Args a) {
   }
 
   f32x4 rq[4], rc[4];
+  float rcy = 0.0f;
   auto gload = [&](int64_t step) {
     const int64_t ct = t_begin + step / nkc;
     const int64_t k = (int64_t)(step % nkc) * F_KC + sk;
+    if ((step % nkc) == 0 && tid < F_CT) {       // first chunk of a tile: its 128 per-candidate scalars ride along
+      int64_t j = ct * F_CT + tid;
+      if (j > a.m - 1) j = a.m - 1;
+      rcy = a.cy[j];
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       rq[i] = load4<VEC4>(a.X, qsrc[i], k, a.d, a.dtype);
@@ -122,7 +129,8 @@ __global__ __launch_bounds__(F_NT) void scan_f32_kernel(ScanF32Args a) {
       rc[i] = load4<VEC4>(a.Y, j, k, a.d, a.dtype);
     }
   };
-  auto swrite = [&](int buf) {
+  auto swrite = [&](int buf, int64_t step) {
+    if ((step % nkc) == 0 && tid < F_CT) cys[((step / nkc) & 1) * F_CT + tid] = rcy;
     float* qd = Qs + buf * F_QT * F_LD + srow * F_LD + sk;
     float* cd = Cs + buf * F_CT * F_LD + srow * F_LD + sk;
 #pragma unroll
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(F_NT) void scan_f32_kernel(ScanF32Args a) {
 
   if (steps > 0) {
     gload(0);
-    swrite(0);
+    swrite(0, 0);
   }
   __syncthreads();
 
@@ -173,12 +181,14 @@ __global__ __launch_bounds__(F_NT) void scan_f32_kernel(ScanF32Args a) {
         const int64_t cand0 = ct * F_CT + 32 * t;
         float cj[16];
         bool jv[16];
+        const float* cyt = cys + ((s / nkc) & 1) * F_CT + 32 * t + 4 * half;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t j = cand0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          jv[r] = j < a.m;
-          cj[r] = a.cy[jv[r] ? j : 0];
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 c4 = *reinterpret_cast<const f32x4*>(cyt + 8 * g);
+          cj[4 * g + 0] = c4[0]; cj[4 * g + 1] = c4[1]; cj[4 * g + 2] = c4[2]; cj[4 * g + 3] = c4[3];
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) jv[r] = (cand0 + (r & 3) + 8 * (r >> 2) + 4 * half) < a.m;
         if (metric == MMF_DOT) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) key[t][r] = acc[t][r];
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(F_NT) void scan_f32_kernel(ScanF32Args a) {
       }
     }
 
-    if (s + 1 < steps) swrite(buf ^ 1);
+    if (s + 1 < steps) swrite(buf ^ 1, s + 1);
     __syncthreads();
   }
 
@@ -296,7 +306,7 @@ int scan_f32_cap(int kk) {
 }
 
 static size_t scan_f32_lds(int cap) {
-  return sizeof(float) * (2 * F_QT * F_LD + 2 * F_CT * F_LD) + (size_t)cap * F_NT * 8;
+  return sizeof(float) * (2 * F_QT * F_LD + 2 * F_CT * F_LD + 2 * F_CT) + (size_t)cap * F_NT * 8;
 }
 
 template <int MODE, int CAP>
