@@ -16,6 +16,8 @@
 //
 // Replaces: torch.mm + 3 elementwise passes, build_hypergraph/similarity_kernel.py:43-52, 79-84, 122;
 //           sklearn brute-force kneighbors, build_hypergraph/preprocess_hypergraph.py:379-382.
+#include <stdlib.h>
+
 #include "mmf_dev.h"
 #include "mmf_host.h"
 
@@ -45,6 +47,7 @@ struct ScanF32Args {
   // dense epilogue
   float* out;
   const float* P; int dp; float neg_lambda_g;
+  int debug;   // MMF_F32_DEBUG (timing-only ablations): 1 skip epilogue, 2 skip staging
 };
 
 template <bool VEC4>
@@ -121,12 +124,25 @@ __global__ __launch_bounds__(F_NT) void scan_f32_kernel(ScanF32Args a) {
       if (j > a.m - 1) j = a.m - 1;
       rcy = a.cy[j];
     }
+    const int64_t kbase = (int64_t)(step % nkc) * F_KC;
+    if (VEC4 && kbase + F_KC <= a.d) {          // full chunk (wave-uniform): plain 16-byte loads, no predicates
+      const float* xf = reinterpret_cast<const float*>(a.X);
+      const float* yf = reinterpret_cast<const float*>(a.Y);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      rq[i] = load4<VEC4>(a.X, qsrc[i], k, a.d, a.dtype);
-      int64_t j = ct * F_CT + srow + 32 * i;
-      if (j > a.m - 1) j = a.m - 1;
-      rc[i] = load4<VEC4>(a.Y, j, k, a.d, a.dtype);
+      for (int i = 0; i < 4; ++i) {
+        rq[i] = *reinterpret_cast<const f32x4*>(xf + qsrc[i] * a.d + k);
+        int64_t j = ct * F_CT + srow + 32 * i;
+        if (j > a.m - 1) j = a.m - 1;
+        rc[i] = *reinterpret_cast<const f32x4*>(yf + j * a.d + k);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rq[i] = load4<VEC4>(a.X, qsrc[i], k, a.d, a.dtype);
+        int64_t j = ct * F_CT + srow + 32 * i;
+        if (j > a.m - 1) j = a.m - 1;
+        rc[i] = load4<VEC4>(a.Y, j, k, a.d, a.dtype);
+      }
     }
   };
   auto swrite = [&](int buf, int64_t step) {
@@ -157,76 +173,78 @@ __global__ __launch_bounds__(F_NT) void scan_f32_kernel(ScanF32Args a) {
 
   for (int64_t s = 0; s < steps; ++s) {
     const int buf = (int)(s & 1);
-    if (s + 1 < steps) gload(s + 1);
+    if (s + 1 < steps && !(a.debug & 2)) gload(s + 1);
 
     const float* Qb = Qs + buf * F_QT * F_LD + (32 * wave + c) * F_LD + half;
     const float* Cb = Cs + buf * F_CT * F_LD + c * F_LD + half;
+    // operands of k-step k2+1 are read from LDS before the MFMAs of k-step k2 issue (one wave per SIMD:
+    // nothing else hides the LDS latency); the interleave is pinned for the scheduler
+    float bn = Qb[0];
+    float avn[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) avn[t] = Cb[t * 32 * F_LD];
 #pragma unroll
     for (int k2 = 0; k2 < F_KC / 2; ++k2) {
-      const float b = Qb[2 * k2];
+      const float b = bn;
+      float av[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float av = Cb[t * 32 * F_LD + 2 * k2];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[t], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) av[t] = avn[t];
+      if (k2 + 1 < F_KC / 2) {
+        bn = Qb[2 * (k2 + 1)];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) avn[t] = Cb[t * 32 * F_LD + 2 * (k2 + 1)];
       }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], b, acc[t], 0, 0, 0);
+      if (k2 + 1 < F_KC / 2) __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     }
 
-    if ((int)(s % nkc) == nkc - 1) {
+    if ((int)(s % nkc) == nkc - 1 && !(a.debug & 1)) {
       const int64_t ct = t_begin + s / nkc;
-      f32x16 key[4];
-      float mx = kNegInf;
-      // keys in three wave-uniform flavours (no per-element switch): dot | dot/(r*c) | nl*((r+c)-2dot)
+      // one 32 x 32 sub-tile at a time (keeping all four key vectors live costs 64 VGPRs and pushes the
+      // staging registers of the next chunk into AGPRs, i.e. a vmcnt(0) in front of the MFMA block)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int64_t cand0 = ct * F_CT + 32 * t;
-        float cj[16];
-        bool jv[16];
         const float* cyt = cys + ((s / nkc) & 1) * F_CT + 32 * t + 4 * half;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 c4 = *reinterpret_cast<const f32x4*>(cyt + 8 * g);
-          cj[4 * g + 0] = c4[0]; cj[4 * g + 1] = c4[1]; cj[4 * g + 2] = c4[2]; cj[4 * g + 3] = c4[3];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) jv[r] = (cand0 + (r & 3) + 8 * (r >> 2) + 4 * half) < a.m;
+        f32x16 key;
+        // keys in three wave-uniform flavours (no per-element switch): dot | dot/(r*c) | nl*((r+c)-2dot)
         if (metric == MMF_DOT) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) key[t][r] = acc[t][r];
+          for (int r = 0; r < 16; ++r) key[r] = acc[t][r];
         } else if (metric == MMF_COSINE) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) key[t][r] = key_from_dot<MMF_COSINE>(acc[t][r], ri, cj[r], 0.0f);
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(cyt + 8 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) key[4 * g + i] = key_from_dot<MMF_COSINE>(acc[t][4 * g + i], ri, c4[i], 0.0f);
+          }
         } else {
           const float nl = (metric == MMF_RBF) ? a.neg_lambda : -1.0f;  // (-1)*sq == -sq exactly
 #pragma unroll
-          for (int r = 0; r < 16; ++r) key[t][r] = key_from_dot<MMF_RBF>(acc[t][r], ri, cj[r], nl);
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(cyt + 8 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) key[4 * g + i] = key_from_dot<MMF_RBF>(acc[t][4 * g + i], ri, c4[i], nl);
+          }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          key[t][r] = jv[r] ? key[t][r] : kNegInf;
+          const bool jv = (cand0 + (r & 3) + 8 * (r >> 2) + 4 * half) < a.m;
+          key[r] = jv ? key[r] : kNegInf;
           acc[t][r] = 0.0f;
         }
-        if constexpr (MODE == MODE_SCAN) mx = fmaxf(mx, max16(key[t]));
-      }
-      if constexpr (MODE == MODE_SCAN) {
-        if (__any(mx >= list.thr)) {
-          // one call site for the slow path: walk the four sub-tiles with a uniform runtime index
-#pragma unroll 1
-          for (int t = 0; t < 4; ++t) {
-            const f32x16 v = (t == 0) ? key[0] : (t == 1) ? key[1] : (t == 2) ? key[2] : key[3];
-            if (__any(max16(v) >= list.thr))
-              list.template offer_tile<true>(v, (uint32_t)(ct * F_CT + 32 * t), half, a.kk, 0.0f);
-          }
-        }
-      } else {
-        if (qvalid) {
-          float* orow = a.out + qrow * a.m;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
+        if constexpr (MODE == MODE_SCAN) {
+          if (__any(max16(key) >= list.thr)) list.template offer_tile<true>(key, (uint32_t)cand0, half, a.kk, 0.0f);
+        } else {
+          if (qvalid) {
+            float* orow = a.out + qrow * a.m;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int64_t j = ct * F_CT + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+              const int64_t j = cand0 + (r & 3) + 8 * (r >> 2) + 4 * half;
               if (j < a.m) {
-                float v = (metric == MMF_RBF) ? expf(key[t][r]) : key[t][r];
+                float v = (metric == MMF_RBF) ? expf(key[r]) : key[r];
                 if (a.P) {
                   // K_g from the positions, canonical chains over dp (similarity_kernel.py:79-84, 122)
                   float ni = 0.f, nj = 0.f, dp_ = 0.f;
@@ -247,7 +265,7 @@ __global__ __launch_bounds__(F_NT) void scan_f32_kernel(ScanF32Args a) {
       }
     }
 
-    if (s + 1 < steps) swrite(buf ^ 1, s + 1);
+    if (s + 1 < steps && !(a.debug & 2)) swrite(buf ^ 1, s + 1);
     __syncthreads();
   }
 
@@ -344,6 +362,7 @@ int launch_scan_f32(const ScanProblem& p, const CandLists& L, hipStream_t s, int
   if (grid_out) *grid_out = (int)grid;
   const bool v4 = can_vec4(p.X, p.Y, p.d, p.dtype);
   a.metric = p.metric;
+  { const char* e = getenv("MMF_F32_DEBUG"); a.debug = e ? atoi(e) : 0; }
   if (L.cap == 16) return launch_f32_t<MODE_SCAN, 16>(a, v4, grid, s);
   if (L.cap == 32) return launch_f32_t<MODE_SCAN, 32>(a, v4, grid, s);
   set_error("scan_f32: unsupported list capacity %d", L.cap);
