@@ -157,7 +157,8 @@ def main() -> None:
             "dtype": {1: "f32", 2: "f16 MFMA scan + f32 exact re-rank", 3: "bf16 MFMA scan + f32 exact re-rank"}[prec],
             "data": "synthetic",
             "config": {"workload": f"N={n} d={d} single-modality {args.metric} + top-{k}, self excluded, f32 features",
-                       "rows_per_rank": hi - lo, "parallelism": f"row-shard x{world}, one all-gather of the feature shard",
+                       "rows_per_rank": hi - lo, "parallelism": (f"row-shard x{world}; 16-bit operand shards all-gathered, f32 shard all-gather overlapped with the scan"
+                                       if world > 1 else "single GPU"),
                        "scan_kernel": SCAN_NAME[prec], "col_splits": stats["col_splits"],
                        "scan_grid": stats["scan_grid"], "fallback_rows": stats["fallback_rows"],
                        "candidates_per_row": stats["candidates"] / max(1, hi - lo)},
