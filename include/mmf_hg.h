@@ -173,6 +173,40 @@ int mmf_simtopk_prepared(const void* X, int64_t n, const void* Y, int64_t m, int
                          int device_id, void* hip_stream);
 
 /*
+ * Paneled variant of mmf_simtopk_prepared: the candidate-side 16-bit operands arrive as n_panels separate
+ * blocks (e.g. the chunks of a pipelined all-gather) and each block is scanned by its own launch as soon as
+ * its `ready_event` (a hipEvent_t, or NULL) has fired, so the exchange of block p+1 overlaps the scan of
+ * block p.  Launches hand their per-row thresholds on to the next, so later panels start warm.
+ *   panel column i  <->  column  id_base + (i / seg_len) * seg_stride + i % seg_len  of Y
+ *   (seg_len == 0: id_base + i).  With P ranks owning `rows` rows each and chunk c of S holding rows
+ *   [c*rows/S, (c+1)*rows/S) of every rank in rank order: seg_len = rows/S, seg_stride = rows, id_base = c*rows/S.
+ *   Z  [m_pad, padded_dim] rows past m zero;  cb [m_pad] entries past m -inf;  m_pad % 256 == 0, plus 256 rows /
+ *   entries of readable slack behind each.
+ * c_scal [m]: candidate-side row scalars in Y's (global) row order.  Everything else as mmf_simtopk_prepared.
+ * Result bits are those of mmf_simtopk on the same X, Y.  No reference counterpart.
+ */
+typedef struct mmf_panel {
+  const void*  Z;
+  const float* cb;
+  int64_t m;
+  int64_t m_pad;
+  int64_t seg_len;
+  int64_t seg_stride;
+  int64_t id_base;
+  void*   ready_event;
+} mmf_panel;
+
+int mmf_simtopk_panels(const void* X, int64_t n, const void* Y, int64_t m, int64_t d,
+                       int in_dtype, int metric, float lambda, int k, int exclude_self,
+                       int64_t row_offset, int64_t col_offset,
+                       const mmf_prepared_side* q, const float* c_scal,
+                       const mmf_panel* panels, int n_panels,
+                       const float* maxima, int operand,
+                       int64_t* out_idx, float* out_val,
+                       const mmf_simtopk_opts* opts, mmf_simtopk_stats* stats,
+                       int device_id, void* hip_stream);
+
+/*
  * Merge two sorted [n,k] partial results into one (column-panel streaming, cross-shard merges).
  * Order and tie-break as above; an id present in both inputs is kept once.  ids < 0 are padding.
  * No reference counterpart (the reference is single-device).

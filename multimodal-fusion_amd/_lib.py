@@ -25,6 +25,12 @@ class PreparedSide(ctypes.Structure):
                 ("un", ctypes.c_void_p), ("cb", ctypes.c_void_p)]
 
 
+class Panel(ctypes.Structure):
+    _fields_ = [("Z", ctypes.c_void_p), ("cb", ctypes.c_void_p), ("m", ctypes.c_int64), ("m_pad", ctypes.c_int64),
+                ("seg_len", ctypes.c_int64), ("seg_stride", ctypes.c_int64), ("id_base", ctypes.c_int64),
+                ("ready_event", ctypes.c_void_p)]
+
+
 class SimtopkStats(ctypes.Structure):
     _fields_ = [("scan_ms", ctypes.c_float), ("prep_ms", ctypes.c_float), ("rerank_ms", ctypes.c_float),
                 ("fallback_ms", ctypes.c_float), ("candidates", ctypes.c_int64), ("fallback_rows", ctypes.c_int64),
@@ -38,7 +44,7 @@ class SimtopkStats(ctypes.Structure):
 _lib = None
 
 EXPORTS = ["mmf_version", "mmf_last_error", "mmf_simtopk", "mmf_simtopk_ex", "mmf_row_scalars", "mmf_prep_rows",
-           "mmf_simtopk_prepared", "mmf_padded_dim", "mmf_topk_merge", "mmf_edge_cosine",
+           "mmf_simtopk_prepared", "mmf_simtopk_panels", "mmf_padded_dim", "mmf_topk_merge", "mmf_edge_cosine",
            "mmf_sim_dense", "mmf_sim_dense_combined", "mmf_offdiag_lower_median", "mmf_threshold_edges",
            "mmf_release_workspaces"]
 
@@ -64,6 +70,9 @@ def lib() -> ctypes.CDLL:
     L.mmf_simtopk_prepared.argtypes = [vp, i64, vp, i64, i64, ci, ci, f32, ci, ci, i64, i64,
                                        ctypes.POINTER(PreparedSide), ctypes.POINTER(PreparedSide), i64, vp, ci, vp, vp,
                                        ctypes.POINTER(SimtopkOpts), ctypes.POINTER(SimtopkStats), ci, vp]
+    L.mmf_simtopk_panels.argtypes = [vp, i64, vp, i64, i64, ci, ci, f32, ci, ci, i64, i64,
+                                     ctypes.POINTER(PreparedSide), vp, ctypes.POINTER(Panel), ci, vp, ci, vp, vp,
+                                     ctypes.POINTER(SimtopkOpts), ctypes.POINTER(SimtopkStats), ci, vp]
     L.mmf_topk_merge.argtypes = [vp, vp, vp, vp, i64, ci, vp, vp, ci, vp]
     L.mmf_edge_cosine.argtypes = [vp, i64, i64, ci, vp, i64, vp, ci, vp]
     L.mmf_sim_dense.argtypes = [vp, i64, vp, i64, i64, ci, ci, f32, vp, ci, vp]

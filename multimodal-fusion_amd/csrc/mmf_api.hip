@@ -65,7 +65,8 @@ int launch_prep_half(const void* X, int64_t n, int64_t d, int dtype, int metric,
 int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float* q_zn, const float* q_rn,
                     const float* q_un, const uint32_t* maxima, int64_t n_rows, int64_t m, int64_t m_pad, int dp,
                     int64_t d, bool f16, int metric, int kk, int col_splits, const CandLists& L, void* scratch,
-                    hipStream_t s, int* grid_out);
+                    const ScanB16Panel& pn, hipStream_t s, int* grid_out);
+int launch_scan_b16_audit(const ScanB16Panel& pn, uint32_t* overflow, int64_t n_rows, hipStream_t s);
 size_t scan_b16_scratch_bytes(int64_t n_rows, int col_splits, int dp);
 int scan_b16_queries_per_block(int dp);
 
@@ -128,6 +129,9 @@ struct FastOperands {
   const float* c_cb; const uint32_t* max_c;
   int64_t m_pad_tiles;   // candidate rows covered by tiles (multiple of 256)
   int dp; bool f16;
+  // paneled scan (mmf_simtopk_panels): the candidate operands come as n_panels separate blocks, each scanned by
+  // its own launch once its event has fired; ZC / c_cb / m_pad_tiles above are then unused
+  const mmf_panel* panels = nullptr; int n_panels = 0;
 };
 
 struct FastTail {
@@ -137,16 +141,29 @@ struct FastTail {
   uint32_t *fail_count = nullptr, *cand_total = nullptr, *fb_fail_count = nullptr;
   char* scan_scratch = nullptr;
 
-  int dp;
-  FastTail(int64_t n_, int64_t m_, int kk_, int cap_, int forced_splits, int dp_) : n(n_), m(m_), kk(kk_), cap(cap_), dp(dp_) {
+  int dp, panels;
+  int64_t n_seed;
+  int32_t* seed = nullptr;
+  // a handful of flagged rows skips the matrix-core rescan: all their keys, then a block-wide top-k
+  static constexpr int64_t kRowsExactMax = 48;
+  int64_t rows_exact_cap = 0;
+  float* row_keys = nullptr;
+  // m_panel_min: columns of the smallest panel (== m_ when the scan is one launch); `splits` is per launch
+  FastTail(int64_t n_, int64_t m_, int kk_, int cap_, int forced_splits, int dp_, int panels_ = 1, int64_t m_panel_min = -1)
+      : n(n_), m(m_), kk(kk_), cap(cap_), dp(dp_), panels(panels_) {
     bcap = scan_bf16_cap(kk);
     const int qt = scan_b16_queries_per_block(dp);
-    const int64_t row_blocks = (n + qt - 1) / qt, col_tiles = ((m + 255) / 256 * 256) / 32;
+    if (m_panel_min < 0) m_panel_min = m;
+    const int64_t row_blocks = (n + qt - 1) / qt, col_tiles = ((m_panel_min + 255) / 256 * 256) / 32;
+    n_seed = row_blocks * qt;
     splits = 1;
     if (forced_splits > 0) { while (splits < forced_splits) splits <<= 1; }
     else { while (row_blocks * splits < 256 && splits < 32) splits <<= 1; }
-    while (splits > 1 && (splits > col_tiles || 2 * splits * bcap > 1024)) splits >>= 1;
-    lists = 2 * splits;
+    while (splits > 1 && (splits > col_tiles || 2 * splits * panels * bcap > 1024)) splits >>= 1;
+    lists = 2 * splits * panels;
+    rows_exact_cap = (int64_t(64) << 20) / (4 * (m > 0 ? m : 1));
+    if (rows_exact_cap > kRowsExactMax) rows_exact_cap = kRowsExactMax;
+    if (rows_exact_cap < 1) rows_exact_cap = 1;
     FB = n < 4096 ? n : 4096;   // exact rescans are done in batches of at most FB rows
     fb_splits = pick_splits((FB + 127) / 128, (m + 127) / 128, 0, cap, 0);
     fb_lists = 2 * fb_splits;
@@ -154,7 +171,8 @@ struct FastTail {
   size_t bytes() const {
     return ws_bytes((size_t)n * lists, 4) + ws_bytes((size_t)n * lists * bcap, 4) + 2 * ws_bytes(n, 4) + ws_bytes(4, 4) +
            ws_bytes(256, 4) + ws_bytes((size_t)FB * fb_lists, 4) + ws_bytes((size_t)FB * fb_lists * cap, 4) +
-           2 * ws_bytes(FB, 4) + ws_bytes(4, 4) + ws_bytes(scan_b16_scratch_bytes(n, splits, dp), 1);
+           2 * ws_bytes(FB, 4) + ws_bytes(4, 4) + ws_bytes(scan_b16_scratch_bytes(n, splits, dp), 1) + ws_bytes(2 * n_seed, 4) +
+           ws_bytes((size_t)rows_exact_cap * m, 4);
   }
   void carve(Workspace& ws) {
     L.cnt = ws.take<uint32_t>((size_t)n * lists);
@@ -171,6 +189,8 @@ struct FastTail {
     fb_fail_rows = ws.take<int32_t>(FB);
     fb_fail_count = ws.take<uint32_t>(4);
     scan_scratch = ws.take<char>(scan_b16_scratch_bytes(n, splits, dp));
+    seed = ws.take<int32_t>(2 * n_seed);
+    row_keys = ws.take<float>((size_t)rows_exact_cap * m);
   }
   int run(const void* X, int64_t n_, const void* Y, int64_t m_, int64_t d, int in_dtype, int metric, float lambda, int k,
           int exclude_self, int64_t row_offset, int64_t col_offset, const FastOperands& fo, int64_t* out_idx,
@@ -180,9 +200,31 @@ struct FastTail {
     MMF_HIP(hipMemsetAsync(cand_total, 0, 1024, s));
     EventTimer t_scan, t_sel, t_fb;
     int grid = 0;
+    MMF_HIP(hipMemsetAsync(seed, 0x80, (size_t)n_seed * 8, s));   // kSeedNone, thresholds and dropped keys
     MMF_TRY(t_scan.start(profile, s));
-    MMF_TRY(launch_scan_b16(fo.ZQ, fo.ZC, fo.c_cb, fo.q_zn, fo.q_rn, fo.q_un, fo.max_c, n, m, fo.m_pad_tiles, fo.dp, d, fo.f16,
-                            metric, kk, splits, L, scan_scratch, s, &grid));
+    ScanB16Panel pn;
+    pn.seed = seed; pn.seed_stride = n_seed;
+    pn.share = (splits > 1 || fo.n_panels > 1) ? 1 : 0;
+    if (fo.n_panels == 0) {
+      MMF_TRY(launch_scan_b16(fo.ZQ, fo.ZC, fo.c_cb, fo.q_zn, fo.q_rn, fo.q_un, fo.max_c, n, m, fo.m_pad_tiles, fo.dp, d, fo.f16,
+                              metric, kk, splits, L, scan_scratch, pn, s, &grid));
+    } else {
+      // one launch per panel, each behind its own arrival event; the launches share the lists (disjoint
+      // slots), the id scratch (they run one after the other) and the per-query thresholds
+      for (int p = 0; p < fo.n_panels; ++p) {
+        const mmf_panel& P = fo.panels[p];
+        if (P.ready_event) MMF_HIP(hipStreamWaitEvent(s, static_cast<hipEvent_t>(P.ready_event), 0));
+        pn.list_base = 2 * splits * p;
+        pn.seg_len = (uint32_t)P.seg_len; pn.seg_stride = (uint32_t)P.seg_stride; pn.id_off = (uint32_t)P.id_base;
+        MMF_TRY(launch_scan_b16(fo.ZQ, P.Z, P.cb, fo.q_zn, fo.q_rn, fo.q_un, fo.max_c, n, P.m, P.m_pad, fo.dp, d, fo.f16,
+                                metric, kk, splits, L, scan_scratch, pn, s, &grid));
+      }
+    }
+    MMF_TRY(launch_scan_b16_audit(pn, L.overflow, n, s));
+    if (const char* e = getenv("MMF_DEBUG_FLAG_ROWS")) {   // test hook: send the first rows down the exact paths
+      const int64_t f = atoll(e);
+      if (f > 0) MMF_HIP(hipMemsetAsync(L.overflow, 1, (size_t)(f < n ? f : n) * 4, s));
+    }
     MMF_TRY(t_scan.stop(s));
     // the f32 rows are first touched here: a caller that is still receiving them (overlapped
     // all-gather) hands in the event that marks their arrival
@@ -205,6 +247,14 @@ struct FastTail {
     const uint32_t h_fail = h_fail4[0];
 
     MMF_TRY(t_fb.start(profile && h_fail > 0, s));
+    if (h_fail > 0 && (int64_t)h_fail <= kRowsExactMax) {
+      for (int64_t off = 0; off < (int64_t)h_fail; off += rows_exact_cap) {
+        SelectProblem fq = q;
+        fq.row_ids = fail_rows + off;
+        fq.n_rows = ((int64_t)h_fail - off < rows_exact_cap) ? ((int64_t)h_fail - off) : rows_exact_cap;
+        MMF_TRY(launch_rows_exact(fq, row_keys, s));
+      }
+    } else
     for (int64_t off = 0; off < (int64_t)h_fail; off += FB) {
       const int64_t nb = ((int64_t)h_fail - off < FB) ? ((int64_t)h_fail - off) : FB;
       MMF_HIP(hipMemsetAsync(FL.overflow, 0, (size_t)nb * 4, s));
@@ -515,6 +565,55 @@ int mmf_simtopk_prepared(const void* X, int64_t n, const void* Y, int64_t m, int
   ft.carve(ws);
   FastOperands fo{static_cast<const uint16_t*>(q->Z), static_cast<const uint16_t*>(c->Z), q->scal, c->scal, q->zn, q->rn, q->un,
                   c->cb, reinterpret_cast<const uint32_t*>(maxima), m_pad, scan_bf16_dp(d), operand == MMF_F16};
+  return ft.run(X, n, Y, m, d, in_dtype, metric, lambda, k, exclude_self, row_offset, col_offset, fo, out_idx, out_val,
+                opts && opts->profile, opts ? opts->select_wait_event : nullptr, stats,
+                operand == MMF_F16 ? MMF_PREC_FAST : MMF_PREC_FAST_BF16, s);
+}
+
+int mmf_simtopk_panels(const void* X, int64_t n, const void* Y, int64_t m, int64_t d, int in_dtype, int metric,
+                       float lambda, int k, int exclude_self, int64_t row_offset, int64_t col_offset,
+                       const mmf_prepared_side* q, const float* c_scal, const mmf_panel* panels, int n_panels,
+                       const float* maxima, int operand, int64_t* out_idx, float* out_val, const mmf_simtopk_opts* opts,
+                       mmf_simtopk_stats* stats, int device_id, void* hip_stream) {
+  MMF_TRY(check_common(X, n, m, d, in_dtype, device_id));
+  if (!Y || !q || !c_scal || !panels || !maxima) { set_error("simtopk_panels: NULL pointer"); return MMF_E_INVALID; }
+  if (metric < MMF_DOT || metric > MMF_RBF) { set_error("simtopk_panels: bad metric %d", metric); return MMF_E_INVALID; }
+  if (metric == MMF_RBF && !(lambda > 0.0f)) { set_error("simtopk_panels: MMF_RBF needs lambda > 0"); return MMF_E_INVALID; }
+  if (operand != MMF_F16 && operand != MMF_BF16) { set_error("simtopk_panels: bad operand"); return MMF_E_INVALID; }
+  if (k < 1) { set_error("simtopk_panels: k must be >= 1"); return MMF_E_INVALID; }
+  if (n_panels < 1 || n_panels > 16) { set_error("simtopk_panels: n_panels must be in 1..16"); return MMF_E_INVALID; }
+  int64_t covered = 0, m_min = m;
+  for (int p = 0; p < n_panels; ++p) {
+    const mmf_panel& P = panels[p];
+    if (!P.Z || !P.cb || P.m < 1 || P.m_pad < P.m || (P.m_pad % 256) != 0 || P.seg_len < 0 || P.id_base < 0 ||
+        (P.seg_len > 0 && (P.seg_stride < P.seg_len || (P.m % P.seg_len) != 0))) {
+      set_error("simtopk_panels: panel %d is malformed", p); return MMF_E_INVALID;
+    }
+    const int64_t last = P.seg_len ? P.id_base + (P.m / P.seg_len - 1) * P.seg_stride + P.seg_len - 1 : P.id_base + P.m - 1;
+    if (last >= m) { set_error("simtopk_panels: panel %d maps past column %lld", p, (long long)m); return MMF_E_INVALID; }
+    covered += P.m;
+    if (P.m < m_min) m_min = P.m;
+  }
+  if (covered != m) { set_error("simtopk_panels: panels cover %lld columns, Y has %lld", (long long)covered, (long long)m); return MMF_E_INVALID; }
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (n == 0) return MMF_OK;
+  {
+    const bool overlap = exclude_self && (row_offset < col_offset + m) && (row_offset + n > col_offset);
+    if (k > m - (overlap ? 1 : 0)) { set_error("simtopk_panels: k exceeds the admissible columns"); return MMF_E_INVALID; }
+  }
+  const int kk = k + (exclude_self ? 1 : 0);
+  if (!scan_bf16_supported(d, kk, in_dtype)) { set_error("simtopk_panels: d = %lld / k = %d not supported by the 16-bit scan", (long long)d, k); return MMF_E_UNSUPPORTED; }
+  const int cap = scan_f32_cap(kk);
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  FastTail ft(n, m, kk, cap, opts ? opts->col_splits : 0, scan_bf16_dp(d), n_panels, m_min);
+  Workspace ws;
+  MMF_TRY(get_workspace(device_id, s, ft.bytes(), &ws));
+  ft.carve(ws);
+  FastOperands fo{static_cast<const uint16_t*>(q->Z), nullptr, q->scal, c_scal, q->zn, q->rn, q->un,
+                  nullptr, reinterpret_cast<const uint32_t*>(maxima), 0, scan_bf16_dp(d), operand == MMF_F16};
+  fo.panels = panels; fo.n_panels = n_panels;
   return ft.run(X, n, Y, m, d, in_dtype, metric, lambda, k, exclude_self, row_offset, col_offset, fo, out_idx, out_val,
                 opts && opts->profile, opts ? opts->select_wait_event : nullptr, stats,
                 operand == MMF_F16 ? MMF_PREC_FAST : MMF_PREC_FAST_BF16, s);

@@ -90,6 +90,15 @@ struct CandLists {
   int cap;
 };
 
+// Where a launch of the 16-bit scan sits inside a paneled scan (all zero: the whole problem in one launch).
+struct ScanB16Panel {
+  int list_base = 0;                                   // first of the row's list slots this launch writes
+  uint32_t seg_len = 0, seg_stride = 0, id_off = 0;    // operand column i -> id_off + (i / seg_len) * seg_stride + i % seg_len
+  int32_t* seed = nullptr;                             // [2][seed_stride]: best proven threshold / best dropped key per query
+  int64_t seed_stride = 0;                             //   (ordered-int encoding), memset to 0x80 before the first launch
+  int share = 0;                                       // more than one workgroup / launch scans each query
+};
+
 struct ScanProblem {
   const void* X; int64_t n;       // query rows
   const void* Y; int64_t m;       // candidate rows (columns of the similarity matrix)
@@ -120,6 +129,8 @@ struct SelectProblem {
   uint32_t* cand_total;                        // optional accumulated candidate count
 };
 int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s);
+// exact top-k of a few rows (p.row_ids) against every column, no candidate lists; keys: p.n_rows * p.m floats
+int launch_rows_exact(const SelectProblem& p, float* keys, hipStream_t s);
 int launch_topk_merge(const int64_t* ia, const float* va, const int64_t* ib, const float* vb,
                       int64_t n, int k, int64_t* io, float* vo, hipStream_t s);
 int launch_edge_cosine(const void* X, int64_t n, int64_t d, int dtype, const int64_t* ei, int64_t E,

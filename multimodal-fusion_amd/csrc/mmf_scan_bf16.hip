@@ -161,6 +161,17 @@ struct ScanB16Args {
   int64_t tiles_per_split;
   int64_t row_blocks;
   int col_splits;            // power of two
+  int conc_splits;           // splits that run side by side (power of two <= 8); the rest follow in later "rounds" of block ids
+  int64_t blocks_per_round;
+  int lists_total;           // lists per query row in cand_cnt / cand_ids (>= list_base + 2 * col_splits)
+  int list_base;             // first list slot written by this launch
+  uint32_t seg_len, seg_stride, id_off;   // column i of ZC is reported as id_off + (i / seg_len) * seg_stride + i % seg_len
+                                          // (seg_len == 0: id_off + i)
+  int32_t* seed;             // [row_blocks * QT] best threshold published for each query by the workgroups / launches
+                             // that scan it (order-preserving int encoding, see seed_enc; memset 0x80 = none)
+  int32_t* lost;             // [row_blocks * QT] best key any of them dropped (same encoding); the row is rescanned
+                             // exactly iff lost >= seed once every launch has finished (audit_kernel)
+  int share;                 // other workgroups scan the same queries: import their thresholds on the way
   int kk;
   int metric;
   int d;
@@ -169,6 +180,13 @@ struct ScanB16Args {
   uint32_t* lids;            // lane-private id slots: [grid][16][B_NT] (global, written on push, read once at the end)
   uint32_t* cand_cnt; uint32_t* cand_ids; uint32_t* overflow;
 };
+
+// Order-preserving float <-> int32 map (an involution) so that thresholds can be merged with atomicMax.
+__device__ __forceinline__ int32_t seed_enc(float f) {
+  const int32_t b = __float_as_int(f);
+  return b >= 0 ? b : (b ^ 0x7fffffff);
+}
+constexpr int32_t kSeedNone = (int32_t)0x80808080;   // hipMemset(0x80) pattern: "no threshold yet"
 
 #define MMF_GLDS(gptr, lptr, size) \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), \
@@ -203,14 +221,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(Sc
 
   // XCD-aware block -> (row block, split): blocks that share blockIdx % 8 share an XCD (observed
   // round-robin placement; speed only) and are given the same column range, so its tiles are L2 hits.
+  // Splits beyond the `conc_splits` that run side by side follow in later rounds of block ids, i.e. later in
+  // dispatch order: their workgroups start from the thresholds the earlier ones published (a.seed).
   int64_t rb;
   int split;
   {
-    const int S = a.col_splits;
-    const int64_t q = blockIdx.x >> 3;
-    const int x = blockIdx.x & 7;
-    if (S <= 8) { split = x % S; rb = q * (8 / S) + x / S; }
-    else { const int g = S >> 3; split = x + 8 * (int)(q % g); rb = q / g; }
+    const int CS = a.conc_splits;
+    const int64_t round = blockIdx.x / a.blocks_per_round;
+    const int64_t j = blockIdx.x - round * a.blocks_per_round;
+    const int64_t q = j >> 3;
+    const int x = (int)(j & 7);
+    split = (int)round * CS + x % CS;
+    rb = q * (8 / CS) + x / CS;
   }
   if (rb >= a.row_blocks) return;
   const int64_t q0 = rb * QT;
@@ -243,6 +265,27 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(Sc
   SlotList<CAP, NT> list;
   list.init(lkeys + tid, lids + tid);
   if (!qvalid) list.thr = __builtin_huge_valf();
+  // Thresholds are shared between the workgroups (and launches) that scan different columns for the same
+  // queries: any list's threshold bounds the approximate key of every member of the final top-k, whatever
+  // columns it sits in.  sync_seed publishes this lane's threshold when it has risen (and is not the product
+  // of a dropped key) and adopts the best one published so far; it runs at the start and every 64 tiles.
+  float pub = -kFltMax;
+  auto sync_seed = [&]() {
+    if (!qvalid) return;
+    if (list.thr > pub && list.thr > list.lost) {
+      pub = list.thr;
+      atomicMax(a.seed + qpos, seed_enc(pub));
+    }
+    if (!a.share) return;
+    const int32_t o = __hip_atomic_load(a.seed + qpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (o > kSeedNone) {
+      const float t = __int_as_float(o >= 0 ? o : (o ^ 0x7fffffff));
+      if (t > list.thr) { list.thr = t; pub = t; }
+    }
+  };
+  if (a.share) sync_seed();
+  // a wave whose queries all start from a published threshold skips the cold-start treatment
+  const bool seeded = !__any(list.thr == -kFltMax);
 
   // resident query fragments: B operand, lane (c, half) holds Z[q0 + 32w + c][16 s + 8 half .. +7]
   u32x4 qf[KS];
@@ -350,7 +393,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(Sc
     if (!(DBG && (a.debug & 1)) && __any(mx >= list.thr)) {
       const uint32_t id0 = id_base + (uint32_t)tt * B_CT;
       // robust (never dropping) path while thresholds are still forming: first 32 tiles of the range
-      const bool cold = (tt < 32) || __any(list.thr == -kFltMax);
+      const bool cold = (!seeded && tt < 32) || __any(list.thr == -kFltMax);
       if (DBG && (a.debug & 8)) {
         const bool willc = __any(list.cnt >= CAP - 1);
         int nh = 0;
@@ -378,6 +421,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(Sc
       }
     }
     if (DBG && (a.debug & 8) && lane == 0) atomicAdd(a.dbg + 5, 1ull);   // tiles
+    if (a.share && (tt & 63) == 63) sync_seed();
   };
 
   // Main loop: TPB tiles per barrier.  Iteration j reads the group of stages holding tiles j*TPB ..
@@ -436,13 +480,27 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(Sc
   __builtin_amdgcn_s_waitcnt(0x0F70);   // the dummy tiles still in flight
 
   list.compact(a.kk, margin);
-  list.finish();
+  sync_seed();
   if (qvalid) {
-    const int64_t lbase = qpos * (2 * a.col_splits) + 2 * split + half;
+    const int64_t lbase = qpos * a.lists_total + a.list_base + 2 * split + half;
     a.cand_cnt[lbase] = (uint32_t)list.cnt;
-    for (int e = 0; e < list.cnt; ++e) a.cand_ids[lbase * CAP + e] = list.id_of(e);
-    if (list.overflow) atomicOr(a.overflow + qpos, 1u);
+    for (int e = 0; e < list.cnt; ++e) {
+      uint32_t id = list.id_of(e);
+      if (a.seg_len) id = (id / a.seg_len) * a.seg_stride + id % a.seg_len;
+      a.cand_ids[lbase * CAP + e] = id + a.id_off;
+    }
+    // Audited loss, settled after the last launch: a dropped candidate matters only if its key reaches the
+    // best threshold ANY list of the row has proven by then.
+    if (list.lost > kNegInf) atomicMax(a.lost + qpos, seed_enc(list.lost) + 16);   // +16 ulp: stored keys carry slot bits
   }
+}
+
+// overflow[row] |= (a key was dropped for the row) && (no list proved a threshold above it)
+__global__ void audit_kernel(const int32_t* seed, const int32_t* lost, uint32_t* overflow, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t l = lost[i];
+  if (l > kSeedNone && l >= seed[i]) overflow[i] = 1u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -482,14 +540,21 @@ static size_t scan_b16_lds(int ks, int nw, int tpb, int cap) {
 
 int scan_b16_queries_per_block(int dp) { return 32 * waves_for_dp(dp); }
 
+// splits of a row block that run side by side; the remaining col_splits / conc follow in later rounds
+static int conc_splits_for(int64_t row_blocks, int col_splits) {
+  int cs = 1;
+  while (cs < 8 && cs < col_splits && row_blocks * cs < 256) cs <<= 1;
+  return cs;
+}
+static int64_t scan_b16_round_blocks(int64_t row_blocks, int cs) {
+  const int per = 8 / cs;                                 // row blocks per group of 8 block ids
+  return ((row_blocks + per - 1) / per) * 8;
+}
 static int64_t scan_b16_grid(int64_t n_rows, int col_splits, int dp) {
   const int qt = scan_b16_queries_per_block(dp);
   const int64_t row_blocks = (n_rows + qt - 1) / qt;
-  if (col_splits <= 8) {
-    const int per = 8 / col_splits;                       // row blocks per group of 8 block ids
-    return ((row_blocks + per - 1) / per) * 8;
-  }
-  return row_blocks * col_splits;                         // col_splits multiple of 8: exact
+  const int cs = conc_splits_for(row_blocks, col_splits);
+  return scan_b16_round_blocks(row_blocks, cs) * (col_splits / cs);
 }
 
 // bytes of the global id-slot scratch ([grid][16][threads] u32) a launch needs
@@ -514,17 +579,32 @@ static int launch_b16_t(const ScanB16Args& a, bool f16, int64_t grid, hipStream_
   return go(scan_b16_kernel<KS, false, false, NW, TPB, CAP>);
 }
 
+// Settles the audited losses of all scan launches of a problem (call once, after the last one).
+int launch_scan_b16_audit(const ScanB16Panel& pn, uint32_t* overflow, int64_t n_rows, hipStream_t s) {
+  hipLaunchKernelGGL(audit_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, s, pn.seed, pn.seed + pn.seed_stride,
+                     overflow, n_rows);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+
 // col_splits must be a power of two.  Lists are indexed by query position, cap = B_CAP.
 int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float* q_zn, const float* q_rn,
                     const float* q_un, const uint32_t* maxima, int64_t n_rows, int64_t m, int64_t m_pad, int dp,
                     int64_t d, bool f16, int metric, int kk, int col_splits, const CandLists& L, void* scratch,
-                    hipStream_t s, int* grid_out) {
+                    const ScanB16Panel& pn, hipStream_t s, int* grid_out) {
   ScanB16Args a{};
   a.ZQ = ZQ; a.ZC = ZC; a.cb = cb; a.q_zn = q_zn; a.q_rn = q_rn; a.q_un = q_un; a.maxima = maxima;
   a.n_rows = n_rows; a.m = m; a.tiles_total = m_pad / B_CT;
   a.tiles_per_split = (a.tiles_total + col_splits - 1) / col_splits;
   a.row_blocks = (n_rows + scan_b16_queries_per_block(dp) - 1) / scan_b16_queries_per_block(dp);
   a.col_splits = col_splits; a.kk = kk; a.metric = metric; a.d = (int)d;
+  a.conc_splits = conc_splits_for(a.row_blocks, col_splits);
+  a.blocks_per_round = scan_b16_round_blocks(a.row_blocks, a.conc_splits);
+  a.lists_total = L.lists; a.list_base = pn.list_base;
+  a.seg_len = pn.seg_len; a.seg_stride = pn.seg_stride; a.id_off = pn.id_off;
+  a.seed = pn.seed; a.lost = pn.seed + pn.seed_stride; a.share = pn.share;
+  if (!pn.seed) { set_error("scan_b16: threshold buffers missing"); return MMF_E_INTERNAL; }
+  if (pn.list_base + 2 * col_splits > L.lists) { set_error("scan_b16: list slots out of range"); return MMF_E_INTERNAL; }
   {
     const char* dbg = getenv("MMF_SCAN_DEBUG");
     a.debug = dbg ? atoi(dbg) : 0;

@@ -338,6 +338,143 @@ int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// exact top-k of a FEW rows against every column (the rows the fast path could not certify, when
+// there are too few of them to feed the matrix-core rescan): rowkeys writes all m canonical keys of
+// a row, rowtopk picks k of them under (key desc, id asc).
+//   rowkeys: grid (column blocks of 256, rows); a wave owns 64 columns, one lane per column.  Y is
+//   read in coalesced [64 columns x 32 k] tiles through LDS (stride 33: conflict-free for both the
+//   row-wise fill and the lane-per-row walk); the chains run k-ascending as everywhere else.
+// ------------------------------------------------------------------------------------------------
+struct RowKeysArgs {
+  const void* X; const void* Y; int64_t m, d; int dtype; float neg_lambda; int exclude_self;
+  int64_t row_offset, col_offset; const float* rx; const float* cy; const int32_t* row_ids; int64_t n_rows;
+  float* keys;   // [rows][m]
+};
+
+constexpr int RK_ROWS = 4;   // rows that share one pass over Y
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void rowkeys_kernel(RowKeysArgs a) {
+  __shared__ float ytile[4][64][33];
+  __shared__ float xrow[RK_ROWS][32];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t g0 = (int64_t)blockIdx.y * RK_ROWS;               // first of this block's rows in row_ids
+  int64_t row[RK_ROWS];
+#pragma unroll
+  for (int r = 0; r < RK_ROWS; ++r) row[r] = a.row_ids[(g0 + r < a.n_rows) ? (g0 + r) : g0];
+  const int64_t c0 = ((int64_t)blockIdx.x * 4 + wave) * 64;      // first column of this wave
+  const int64_t col = c0 + lane;
+  float acc[RK_ROWS];
+#pragma unroll
+  for (int r = 0; r < RK_ROWS; ++r) acc[r] = 0.0f;
+  for (int64_t k0 = 0; k0 < a.d; k0 += 32) {
+    const int kc = (a.d - k0 < 32) ? (int)(a.d - k0) : 32;
+    __syncthreads();                                               // previous chunk consumed
+    if (threadIdx.x < 32 * RK_ROWS && (threadIdx.x & 31) < kc)
+      xrow[threadIdx.x >> 5][threadIdx.x & 31] = ld_elem(a.X, row[threadIdx.x >> 5] * a.d + k0 + (threadIdx.x & 31), a.dtype);
+    for (int r = 0; r < 64; r += 2) {                              // two tile rows per instruction, lanes along k
+      const int rr = r + (lane >> 5), kl = lane & 31;
+      const int64_t cr = c0 + rr;
+      if (cr < a.m && kl < kc) ytile[wave][rr][kl] = ld_elem(a.Y, cr * a.d + k0 + kl, a.dtype);
+    }
+    __syncthreads();
+    if (col < a.m) {
+      for (int k = 0; k < kc; ++k) {
+        const float y = ytile[wave][lane][k];
+#pragma unroll
+        for (int r = 0; r < RK_ROWS; ++r) acc[r] = __builtin_fmaf(xrow[r][k], y, acc[r]);
+      }
+    }
+  }
+  if (col < a.m) {
+#pragma unroll
+    for (int r = 0; r < RK_ROWS; ++r) {
+      if (g0 + r >= a.n_rows) break;
+      const bool self = a.exclude_self && (a.col_offset + col == a.row_offset + row[r]);
+      float kx = key_from_dot<METRIC>(acc[r], a.rx[row[r]], a.cy[col], a.neg_lambda);
+      if (self || kx != kx) kx = kNegInf;                          // NaN keys rank last, as in select
+      a.keys[(g0 + r) * a.m + col] = kx;
+    }
+  }
+}
+
+struct RowTopkArgs {
+  const float* keys; int64_t m; int k; int exclude_self; int64_t row_offset, col_offset; const int32_t* row_ids;
+  int64_t* out_idx; float* out_val;
+};
+
+template <int METRIC>
+__global__ __launch_bounds__(1024) void rowtopk_kernel(RowTopkArgs a) {
+  __shared__ float wk[16];
+  __shared__ uint32_t wi[16];
+  __shared__ float pk_s;
+  __shared__ uint32_t pi_s;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t row = a.row_ids[blockIdx.x];
+  const float* kr = a.keys + (int64_t)blockIdx.x * a.m;
+  const int64_t self = a.exclude_self ? (a.row_offset + row - a.col_offset) : -1;
+  float pk = 0.0f;            // previous pick; round t takes the best entry ranked strictly after it
+  uint32_t pi = kNoIdx;
+  for (int t = 0; t < a.k; ++t) {
+    float bk = kNegInf;
+    uint32_t bi = kNoIdx;
+    for (int64_t j = threadIdx.x; j < a.m; j += 1024) {
+      if (j == self) continue;
+      const float kj = kr[j];
+      const uint32_t ij = (uint32_t)j;
+      if (t > 0 && !better(pk, pi, kj, ij)) continue;              // already emitted (or the pick itself)
+      if (bi == kNoIdx || better(kj, ij, bk, bi)) { bk = kj; bi = ij; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ok = __shfl_xor(bk, o);
+      const uint32_t oi = (uint32_t)__shfl_xor((int)bi, o);
+      if (oi != kNoIdx && (bi == kNoIdx || better(ok, oi, bk, bi))) { bk = ok; bi = oi; }
+    }
+    if (lane == 0) { wk[wave] = bk; wi[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float fk = wk[0];
+      uint32_t fi = wi[0];
+      for (int w = 1; w < 16; ++w)
+        if (wi[w] != kNoIdx && (fi == kNoIdx || better(wk[w], wi[w], fk, fi))) { fk = wk[w]; fi = wi[w]; }
+      pk_s = fk; pi_s = fi;
+      a.out_idx[row * a.k + t] = a.col_offset + (int64_t)fi;
+      a.out_val[row * a.k + t] = val_from_key<METRIC>(fk);
+    }
+    __syncthreads();
+    pk = pk_s; pi = pi_s;
+  }
+}
+
+template <int METRIC>
+static int launch_rows_exact_m(const RowKeysArgs& ka, const RowTopkArgs& ta, int64_t rows, hipStream_t s) {
+  hipLaunchKernelGGL((rowkeys_kernel<METRIC>), dim3((unsigned)((ka.m + 255) / 256), (unsigned)((rows + RK_ROWS - 1) / RK_ROWS)), dim3(256), 0, s, ka);
+  MMF_LAUNCH_CHECK();
+  hipLaunchKernelGGL((rowtopk_kernel<METRIC>), dim3((unsigned)rows), dim3(1024), 0, s, ta);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+
+// p.row_ids / p.n_rows name the rows; keys: scratch of p.n_rows * p.m floats.
+int launch_rows_exact(const SelectProblem& p, float* keys, hipStream_t s) {
+  if (p.n_rows <= 0) return MMF_OK;
+  if (!p.row_ids) { set_error("rows_exact: row list missing"); return MMF_E_INTERNAL; }
+  RowKeysArgs ka{p.X, p.Y, p.m, p.d, p.dtype, -p.lambda, p.exclude_self, p.row_offset, p.col_offset, p.rx, p.cy, p.row_ids, p.n_rows, keys};
+  RowTopkArgs ta{keys, p.m, p.k, p.exclude_self, p.row_offset, p.col_offset, p.row_ids, p.out_idx, p.out_val};
+  switch (p.metric) {
+    case MMF_DOT: return launch_rows_exact_m<MMF_DOT>(ka, ta, p.n_rows, s);
+    case MMF_COSINE: return launch_rows_exact_m<MMF_COSINE>(ka, ta, p.n_rows, s);
+    case MMF_NEG_SQ_L2: return launch_rows_exact_m<MMF_NEG_SQ_L2>(ka, ta, p.n_rows, s);
+    case MMF_RBF: return launch_rows_exact_m<MMF_RBF>(ka, ta, p.n_rows, s);
+  }
+  set_error("rows_exact: unsupported metric %d", p.metric);
+  return MMF_E_INVALID;
+}
+
+// ------------------------------------------------------------------------------------------------
 // merge two sorted [n,k] lists; one lane per row
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool better64(float ka, int64_t ia, float kb, int64_t ib) {

@@ -1,8 +1,10 @@
 """Row-sharded multi-GPU similarity + top-k: one process per GPU, rank r owns the rows
-[r*N/P, (r+1)*N/P) and their [N/P, k] outputs.  The only exchange is ONE all-gather of the feature
-shard (RCCL over xGMI when the backend is "nccl"); each rank then scans every column for its own
-rows with mmf_simtopk and the global row/column offsets.  No all-reduce, no all-to-all: outputs are
-row-owned and stay sharded unless `gather_output=True`.
+[r*N/P, (r+1)*N/P) and their [N/P, k] outputs.  The only exchange is an all-gather of the row shards
+(RCCL over xGMI when the backend is "nccl"); each rank then scans every column for its own rows with the
+global row/column offsets.  No all-to-all: outputs are row-owned and stay sharded unless `gather_output=True`.
+
+Two drivers: the simple one (one all-gather of the f32 shard, then mmf_simtopk) and the pipelined one used
+for equal f32 shards (16-bit operands exchanged in chunks under the scan, f32 rows under all of it).
 
 The reference has no distributed code; correctness here means
 sharded(P) == unsharded, bit for bit, which tests/test_distributed_cpu.py checks with gloo and the
@@ -52,13 +54,19 @@ def all_gather_rows(x_local: torch.Tensor, n_total: int, group=None) -> torch.Te
 
 
 def _gather_into(out: torch.Tensor, inp: torch.Tensor, group, async_op: bool = False):
-    """all_gather_into_tensor, with host staging under gloo (rehearsal only)."""
+    """all_gather_into_tensor on flat views (rank-major concatenation; backends differ in which shaped
+    outputs they accept), with host staging under gloo (rehearsal only)."""
+    if not out.is_contiguous():
+        raise ValueError("all-gather output must be contiguous")
+    flat_in = inp.contiguous().view(-1)
+    if flat_in.numel() * dist.get_world_size(group) != out.numel():
+        raise ValueError("all-gather output must hold world_size inputs")
     if inp.is_cuda and dist.get_backend(group) == "gloo":
-        o = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_gather_into_tensor(o, inp.cpu().contiguous(), group=group)
-        out.copy_(o)
+        o = torch.empty((out.numel(),), dtype=out.dtype)
+        dist.all_gather_into_tensor(o, flat_in.cpu(), group=group)
+        out.view(-1).copy_(o)
         return None
-    return dist.all_gather_into_tensor(out, inp.contiguous(), group=group, async_op=async_op)
+    return dist.all_gather_into_tensor(out.view(-1), flat_in, group=group, async_op=async_op)
 
 
 def _allreduce_max(t: torch.Tensor, group) -> None:
@@ -70,63 +78,87 @@ def _allreduce_max(t: torch.Tensor, group) -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
 
 
-def _overlapped_simtopk(x_local, n_total, lo, hi, world, *, metric, lam, k, exclude_self, operand, group, return_stats):
-    """Phase path: the f32 all-gather — needed only by the exact re-rank — is started first
-    and left in flight; each rank prepares the 16-bit operands of its own rows, ranks exchange those
-    (half the bytes) plus five floats per row, and the scan runs on them.  The stream waits for the f32
-    rows only between the scan and the re-rank."""
+def _pick_chunks(rows: int, world: int, chunks: Optional[int]) -> int:
+    """Pieces the operand exchange is cut into (each piece: one all-gather + one scan launch)."""
+    if chunks is not None:
+        if chunks < 1 or rows % chunks:
+            raise ValueError(f"chunks={chunks} must divide the {rows} rows of a shard")
+        return chunks
+    for s in (4, 2):
+        if rows % s == 0 and (rows // s) * world >= 16384:
+            return s
+    return 1
+
+
+def _overlapped_simtopk(x_local, n_total, lo, hi, world, *, metric, lam, k, exclude_self, operand, group, return_stats,
+                        chunks=None, col_splits=0):
+    """Pipelined phase path.  Each rank prepares the 16-bit operands of its own rows; the ranks
+    exchange them in S chunks (chunk c = rows [c*rows/S, (c+1)*rows/S) of every rank), and the scan of chunk c —
+    one launch of mmf_simtopk_panels — runs while chunk c+1 is on the wire.  The f32 all-gather, needed only by
+    the exact re-rank, is issued last and is waited for between the last scan launch and the re-rank.
+    Exposed communication: one small gather (5 floats per row) and the first chunk."""
     from . import ops
     dev = x_local.device
     rows, d = x_local.shape
     dp = ops.padded_dim(d)
-    # local phase
-    scal_l = torch.empty((rows,), dtype=torch.float32, device=dev)
+    S = _pick_chunks(rows, world, chunks)
+    seg = rows // S
+    rows_pad = (rows + 255) // 256 * 256
+    z16 = torch.float16 if operand == "f16" else torch.bfloat16
+    # ---- local phase -------------------------------------------------------------------------------------------
+    pack_l = torch.zeros((5, rows_pad), dtype=torch.float32, device=dev)          # scal, zn, rn, un, cb
     maxn = torch.zeros((1,), dtype=torch.float32, device=dev)
-    ops.row_scalars(x_local, metric, scal_l, maxn)
+    ops.row_scalars(x_local, metric, pack_l[0], maxn)
     if metric != "cosine":
         _allreduce_max(maxn, group)                      # the common power-of-two scale needs the global maximum
-    z16 = torch.float16 if operand == "f16" else torch.bfloat16
-    z_l = torch.empty((rows, dp), dtype=z16, device=dev)
-    pack_l = torch.empty((5, rows), dtype=torch.float32, device=dev)      # scal, zn, rn, un, cb
-    pack_l[0] = scal_l
-    max4 = torch.zeros((4,), dtype=torch.float32, device=dev)
-    ops.prep_rows(x_local, metric, operand, scal_l, maxn, z_l, pack_l[1], pack_l[2], pack_l[3], pack_l[4], max4)
-    # exchange of the prepared operands
-    m_pad = (n_total + 255) // 256 * 256
-    z_full = torch.zeros((m_pad + 256, dp), dtype=z16, device=dev)
-    _gather_into(z_full[:n_total], z_l, group)
-    pack_full = torch.empty((world * 5, rows), dtype=torch.float32, device=dev)
-    _gather_into(pack_full, pack_l, group)
-    pf = pack_full.view(world, 5, rows).permute(1, 0, 2).reshape(5, n_total)
-    side = {}
-    for i, name in enumerate(("scal", "zn", "rn", "un", "cb")):
-        buf = torch.full((m_pad + 256,), float("-inf") if name == "cb" else 0.0, dtype=torch.float32, device=dev)
-        buf[:n_total] = pf[i]
-        side[name] = buf
-    _allreduce_max(max4, group)
-    # Only now the big f32 gather: collectives of one group run in issue order on RCCL's stream, so it
-    # must not sit in front of the small exchanges the scan is waiting for.  It then overlaps the scan.
-    full = torch.empty((n_total, d), dtype=x_local.dtype, device=dev)
-    w_full = _gather_into(full, x_local, group, async_op=True)
-    c = dict(Z=z_full, **side)
-    q = dict(Z=z_full[lo:], scal=side["scal"][lo:], zn=side["zn"][lo:], rn=side["rn"][lo:], un=side["un"][lo:],
-             cb=side["cb"][lo:])
-    ev = None
-    if w_full is not None:                                # the f32 rows: wait only after the scan
+    z_l = torch.empty((rows_pad, dp), dtype=z16, device=dev)
+    if rows_pad != rows:
+        z_l[rows:].zero_()
+    send = torch.empty((5 * rows + 4,), dtype=torch.float32, device=dev)         # per-row scalars + this shard's maxima
+    max4 = send[5 * rows:]
+    max4.zero_()
+    ops.prep_rows(x_local, metric, operand, pack_l[0], maxn, z_l, pack_l[1], pack_l[2], pack_l[3], pack_l[4], max4)
+    send[:5 * rows].view(5, rows).copy_(pack_l[:, :rows])
+    # ---- exchanges, in the order the scan needs them (collectives of a group complete in issue order) ------------
+    recv = torch.empty((world, 5 * rows + 4), dtype=torch.float32, device=dev)
+    _gather_into(recv, send, group)
+    m_c = world * seg
+    m_pad = (m_c + 255) // 256 * 256
+    zc = torch.empty((S, m_pad + 256, dp), dtype=z16, device=dev)
+    zc[:, m_c:].zero_()
+    side_stream = torch.cuda.Stream(device=dev)
+    events = []
+
+    def arrival(work):
+        if work is None:
+            return None
         ev = torch.cuda.Event()
-        side_stream = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(side_stream):
-            w_full.wait()
+            work.wait()
             ev.record(side_stream)
-    out = ops.simtopk_prepared(full[lo:hi], full, q, c, m_pad, max4, operand=operand, metric=metric, lam=lam, k=k,
-                               exclude_self=exclude_self, row_offset=lo, col_offset=0, wait_event=ev,
-                               profile=return_stats, return_stats=return_stats)
-    return out
+        return ev
+    for c in range(S):
+        events.append(arrival(_gather_into(zc[c, :m_c], z_l[c * seg:(c + 1) * seg], group, async_op=True)))
+    full = torch.empty((n_total, d), dtype=x_local.dtype, device=dev)
+    ev_full = arrival(_gather_into(full, x_local, group, async_op=True))
+    # ---- candidate-side scalars out of the small gather (overlaps the chunk exchange) ----------------------------
+    max_all = recv[:, 5 * rows:].max(dim=0).values.contiguous()
+    per_row = recv[:, :5 * rows].view(world, 5, rows)
+    c_scal = per_row[:, 0].reshape(n_total)
+    cb = torch.full((S, m_pad + 256), float("-inf"), dtype=torch.float32, device=dev)
+    cb[:, :m_c] = per_row[:, 4].reshape(world, S, seg).permute(1, 0, 2).reshape(S, m_c)
+    panels = [dict(Z=zc[c], cb=cb[c], m=m_c, m_pad=m_pad, seg_len=seg, seg_stride=rows, id_base=c * seg, event=events[c])
+              for c in range(S)]
+    q = dict(Z=z_l, scal=pack_l[0], zn=pack_l[1], rn=pack_l[2], un=pack_l[3], cb=pack_l[4])
+    return ops.simtopk_panels(x_local, full, q, c_scal, panels, max_all, operand=operand, metric=metric, lam=lam, k=k,
+                              exclude_self=exclude_self, row_offset=lo, col_offset=0, wait_event=ev_full,
+                              col_splits=col_splits, profile=return_stats, return_stats=return_stats)
 
 
 def sharded_simtopk(x_local: torch.Tensor, n_total: int, *, metric="cosine", lam: float = 1.0, k: int = 5,
                     exclude_self: bool = True, precision: str = "auto", group=None, gather_output: bool = False,
-                    op: Optional[Callable] = None, return_stats: bool = False, overlap: Optional[bool] = None):
+                    op: Optional[Callable] = None, return_stats: bool = False, overlap: Optional[bool] = None,
+                    chunks: Optional[int] = None, col_splits: int = 0):
     """Top-k of every local row against ALL n_total rows.
 
     x_local: this rank's [N_r, d] shard (rows shard_bounds(n_total, world, rank)).
@@ -143,11 +175,11 @@ def sharded_simtopk(x_local: torch.Tensor, n_total: int, *, metric="cosine", lam
         from . import ops as _ops
         kk = k + (1 if exclude_self else 0)
         equal = (n_total % world) == 0
-        if equal and precision in ("auto", "fast", "fast_bf16") and _ops.padded_dim(x_local.shape[1]) > 0 and kk <= 8 \
+        if equal and precision in ("auto", "fast", "fast_bf16") and _ops.padded_dim(x_local.shape[1]) > 0 and kk <= 12 \
                 and x_local.dtype == torch.float32:
             out = _overlapped_simtopk(x_local.contiguous(), n_total, lo, hi, world, metric=metric, lam=lam, k=k,
                                       exclude_self=exclude_self, operand="bf16" if precision == "fast_bf16" else "f16",
-                                      group=group, return_stats=return_stats)
+                                      group=group, return_stats=return_stats, chunks=chunks, col_splits=col_splits)
             idx, val = out[0], out[1]
             if gather_output:
                 idx = all_gather_rows(idx, n_total, group)

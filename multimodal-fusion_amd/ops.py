@@ -229,3 +229,35 @@ def simtopk_prepared(X: torch.Tensor, Y: torch.Tensor, q: dict, c: dict, m_pad: 
     if return_stats:
         return idx, val, stats.as_dict()
     return idx, val
+
+
+def simtopk_panels(X: torch.Tensor, Y: torch.Tensor, q: dict, c_scal: torch.Tensor, panels: list, maxima: torch.Tensor, *,
+                   operand: str = "f16", metric="cosine", lam: float = 1.0, k: int = 5, exclude_self: bool = True,
+                   row_offset: int = 0, col_offset: int = 0, profile: bool = False, col_splits: int = 0,
+                   wait_event: Optional[torch.cuda.Event] = None, return_stats: bool = False):
+    """Paneled scan + exact re-rank (mmf_simtopk_panels).  panels: dicts with Z [m_pad+256, dp], cb [m_pad+256], m,
+    m_pad, and optionally seg_len / seg_stride / id_base (panel column -> column of Y) and `event` (a
+    torch.cuda.Event the scan of that panel waits for).  q: query-side dict as for simtopk_prepared."""
+    _need_gpu(X, "simtopk_panels")
+    n, d = X.shape
+    m = Y.shape[0]
+    idx = torch.empty((n, k), dtype=torch.int64, device=X.device)
+    val = torch.empty((n, k), dtype=torch.float32, device=X.device)
+    qs = _lib.PreparedSide(*(ctypes.c_void_p(q[key].data_ptr()) for key in ("Z", "scal", "zn", "rn", "un", "cb")))
+    arr = (_lib.Panel * len(panels))()
+    for i, pn in enumerate(panels):
+        ev = pn.get("event")
+        arr[i] = _lib.Panel(ctypes.c_void_p(pn["Z"].data_ptr()), ctypes.c_void_p(pn["cb"].data_ptr()), int(pn["m"]),
+                            int(pn["m_pad"]), int(pn.get("seg_len", 0)), int(pn.get("seg_stride", 0)),
+                            int(pn.get("id_base", 0)), ctypes.c_void_p(ev.cuda_event) if ev is not None else None)
+    ev = ctypes.c_void_p(wait_event.cuda_event) if wait_event is not None else None
+    opts = _lib.SimtopkOpts(_lib.PRECISIONS["fast"], int(profile), int(col_splits), 0, ev)
+    stats = _lib.SimtopkStats()
+    rc = _lib.lib().mmf_simtopk_panels(_p(X), n, _p(Y), m, d, _DT[X.dtype], _metric(metric), float(lam), int(k),
+                                       int(bool(exclude_self)), int(row_offset), int(col_offset), ctypes.byref(qs),
+                                       _p(c_scal), arr, len(panels), _p(maxima), _OPERAND[operand], _p(idx), _p(val),
+                                       ctypes.byref(opts), ctypes.byref(stats), X.device.index or 0, _stream(X.device))
+    _lib.check(rc, "mmf_simtopk_panels")
+    if return_stats:
+        return idx, val, stats.as_dict()
+    return idx, val

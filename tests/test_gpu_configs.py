@@ -180,6 +180,53 @@ def test_phase_api_equals_single_call(mmf, metric):
         assert torch.equal(i, full_i[lo:hi]) and torch.equal(v, full_v[lo:hi]), (metric, r)
 
 
+@pytest.mark.parametrize("metric,S,splits", [("cosine", 4, 0), ("neg_sq_l2", 2, 4), ("dot", 1, 8), ("rbf", 4, 1)])
+def test_paneled_scan_equals_single_call(mmf, metric, S, splits):
+    """mmf_simtopk_panels on the chunk layout of a pipelined all-gather (chunk c = rows [c*rows/S, (c+1)*rows/S)
+    of every rank, rank-major) == the rows of the single-call result, bit for bit."""
+    N, d, P, k = 16384, 200, 4, 6
+    X = make(N, d, 41) * (1.0 if metric == "cosine" else (0.05 if metric == "rbf" else 3.0))
+    full_i, full_v = mmf.simtopk(X, metric=metric, lam=0.5, k=k)
+    ops = mmf.ops
+    dp = ops.padded_dim(d)
+    rows = N // P
+    seg = rows // S
+    maxn = torch.zeros(1, device="cuda")
+    scal = torch.empty(N, device="cuda")
+    for r in range(P):
+        ops.row_scalars(X[r * rows:(r + 1) * rows], metric, scal[r * rows:(r + 1) * rows], maxn)
+    max4 = torch.zeros(4, device="cuda")
+    Z = torch.zeros((N + 256, dp), dtype=torch.float16, device="cuda")
+    zn, rn, un, cb = (torch.zeros(N + 256, device="cuda") for _ in range(4))
+    for r in range(P):
+        sl = slice(r * rows, (r + 1) * rows)
+        ops.prep_rows(X[sl], metric, "f16", scal[sl], maxn, Z[sl], zn[sl], rn[sl], un[sl], cb[sl], max4)
+    m_c = P * seg
+    m_pad = (m_c + 255) // 256 * 256
+    panels = []
+    for c in range(S):
+        Zc = torch.zeros((m_pad + 256, dp), dtype=torch.float16, device="cuda")
+        cbc = torch.full((m_pad + 256,), float("-inf"), device="cuda")
+        Zc[:m_c] = Z[:N].view(P, S, seg, dp)[:, c].reshape(m_c, dp)
+        cbc[:m_c] = cb[:N].view(P, S, seg)[:, c].reshape(m_c)
+        ev = torch.cuda.Event()
+        ev.record()
+        panels.append(dict(Z=Zc, cb=cbc, m=m_c, m_pad=m_pad, seg_len=seg, seg_stride=rows, id_base=c * seg, event=ev))
+    for r in (0, 3):
+        lo, hi = r * rows, (r + 1) * rows
+        q = dict(Z=Z[lo:], scal=scal[lo:], zn=zn[lo:], rn=rn[lo:], un=un[lo:], cb=cb[lo:])
+        i, v, st = ops.simtopk_panels(X[lo:hi], X, q, scal, panels, max4, metric=metric, lam=0.5, k=k, exclude_self=True,
+                                      row_offset=lo, col_splits=splits, return_stats=True)
+        assert torch.equal(i, full_i[lo:hi]), (metric, r)
+        if metric == "rbf":
+            assert torch.allclose(v, full_v[lo:hi], rtol=0, atol=1e-5)
+        else:
+            assert torch.equal(v, full_v[lo:hi]), (metric, r)
+    with pytest.raises(ValueError):
+        bad = [dict(panels[0], m=m_c - seg)] + panels[1:]                      # panels no longer cover Y
+        ops.simtopk_panels(X[:rows], X, q, scal, bad, max4, metric=metric, lam=0.5, k=k)
+
+
 def test_c5_full_size_shard_of_eight(mmf):
     """BASELINE config 5 at full size: N = 1048576, d = 1024, fp16 features.  One GPU runs what rank 5 of 8
     would (131072 local rows against all 1M columns, 2.8e14 flop) and the oracle checks sampled rows."""

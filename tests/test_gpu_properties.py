@@ -67,3 +67,20 @@ def test_dense_equals_topk_of_dense(mmf):
     assert torch.equal(val, v)                                        # same canonical floats out of both kernels
     ties = (v[:, :-1] == v[:, 1:]).any(dim=1)
     assert torch.equal(idx[~ties], i[~ties])
+
+
+@pytest.mark.parametrize("flag_rows", [1, 5, 48, 49, 300])
+@pytest.mark.parametrize("metric,dtype", [("cosine", torch.float32), ("neg_sq_l2", torch.float32), ("rbf", torch.float16)])
+def test_flagged_rows_take_the_exact_paths(mmf, monkeypatch, flag_rows, metric, dtype):
+    """Rows the fast path cannot certify are redone exactly: up to 48 of them by the row-vs-all kernels,
+    more by the matrix-core rescan.  MMF_DEBUG_FLAG_ROWS flags the first rows artificially."""
+    X = (make(9000, 120, 7, unit=False) * (0.05 if metric == "rbf" else 1.0)).to(dtype)
+    ref = mmf.simtopk(X, metric=metric, lam=0.5, k=4, precision="exact")
+    monkeypatch.setenv("MMF_DEBUG_FLAG_ROWS", str(flag_rows))
+    idx, val, st = mmf.simtopk(X, metric=metric, lam=0.5, k=4, precision="fast", return_stats=True)
+    assert st["fallback_rows"] >= flag_rows
+    assert torch.equal(idx, ref[0]) and torch.equal(val, ref[1])
+    Y = (make(5000, 120, 8, unit=False) * (0.05 if metric == "rbf" else 1.0)).to(dtype)       # rectangular, offsets
+    r2 = mmf.simtopk(X[:2000], Y, metric=metric, lam=0.5, k=4, precision="exact", exclude_self=True, row_offset=1000, col_offset=900)
+    o2 = mmf.simtopk(X[:2000], Y, metric=metric, lam=0.5, k=4, precision="fast", exclude_self=True, row_offset=1000, col_offset=900)
+    assert torch.equal(o2[0], r2[0]) and torch.equal(o2[1], r2[1])
