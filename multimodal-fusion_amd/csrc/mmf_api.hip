@@ -169,7 +169,7 @@ struct FastTail {
     fb_lists = 2 * fb_splits;
   }
   size_t bytes() const {
-    return ws_bytes((size_t)n * lists, 4) + ws_bytes((size_t)n * lists * bcap, 4) + 2 * ws_bytes(n, 4) + ws_bytes(4, 4) +
+    return ws_bytes((size_t)n * lists, 4) + 2 * ws_bytes((size_t)n * lists * bcap, 4) + 3 * ws_bytes(n, 4) + ws_bytes(4, 4) +
            ws_bytes(256, 4) + ws_bytes((size_t)FB * fb_lists, 4) + ws_bytes((size_t)FB * fb_lists * cap, 4) +
            2 * ws_bytes(FB, 4) + ws_bytes(4, 4) + ws_bytes(scan_b16_scratch_bytes(n, splits, dp), 1) + ws_bytes(2 * n_seed, 4) +
            ws_bytes((size_t)rows_exact_cap * m, 4);
@@ -177,6 +177,8 @@ struct FastTail {
   void carve(Workspace& ws) {
     L.cnt = ws.take<uint32_t>((size_t)n * lists);
     L.ids = ws.take<uint32_t>((size_t)n * lists * bcap);
+    L.keys = ws.take<float>((size_t)n * lists * bcap);
+    L.margin = ws.take<float>(n);
     L.overflow = ws.take<uint32_t>(n);
     L.lists = lists; L.cap = bcap;
     fail_rows = ws.take<int32_t>(n);
@@ -190,6 +192,7 @@ struct FastTail {
     fb_fail_count = ws.take<uint32_t>(4);
     scan_scratch = ws.take<char>(scan_b16_scratch_bytes(n, splits, dp));
     seed = ws.take<int32_t>(2 * n_seed);
+    if (lists <= 2) { L.keys = nullptr; L.margin = nullptr; }    // one list pair per row: nothing to prune against
     row_keys = ws.take<float>((size_t)rows_exact_cap * m);
   }
   int run(const void* X, int64_t n_, const void* Y, int64_t m_, int64_t d, int in_dtype, int metric, float lambda, int k,

@@ -88,6 +88,10 @@ struct CandLists {
   uint32_t* overflow;  // [n] nonzero when a list of the row overflowed
   int lists;           // lists per row = 2 * col_splits
   int cap;
+  // 16-bit scan only (else nullptr): the entries' approximate keys and the row's error margin — with several
+  // lists per row, select drops what the union of the lists proves irrelevant before the exact re-rank
+  float* keys = nullptr;
+  float* margin = nullptr;   // [n]
 };
 
 // Where a launch of the 16-bit scan sits inside a paneled scan (all zero: the whole problem in one launch).

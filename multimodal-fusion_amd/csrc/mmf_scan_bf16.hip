@@ -179,6 +179,8 @@ struct ScanB16Args {
   unsigned long long* dbg;   // [8] event counters when debug & 8
   uint32_t* lids;            // lane-private id slots: [grid][16][B_NT] (global, written on push, read once at the end)
   uint32_t* cand_cnt; uint32_t* cand_ids; uint32_t* overflow;
+  float* cand_keys;          // approximate keys of the entries (select prunes with them), or nullptr
+  float* margin_out;         // [n_rows] the queries' error margins, written with cand_keys
 };
 
 // Order-preserving float <-> int32 map (an involution) so that thresholds can be merged with atomicMax.
@@ -488,9 +490,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(Sc
       uint32_t id = list.id_of(e);
       if (a.seg_len) id = (id / a.seg_len) * a.seg_stride + id % a.seg_len;
       a.cand_ids[lbase * CAP + e] = id + a.id_off;
+      if (a.cand_keys) a.cand_keys[lbase * CAP + e] = list.keys[e * NT];
     }
     // Audited loss, settled after the last launch: a dropped candidate matters only if its key reaches the
     // best threshold ANY list of the row has proven by then.
+    if (a.cand_keys && half == 0) a.margin_out[qpos] = margin;
     if (list.lost > kNegInf) atomicMax(a.lost + qpos, seed_enc(list.lost) + 16);   // +16 ulp: stored keys carry slot bits
   }
 }
@@ -616,7 +620,7 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
       a.dbg = dbuf;
     }
   }
-  a.cand_cnt = L.cnt; a.cand_ids = L.ids; a.overflow = L.overflow;
+  a.cand_cnt = L.cnt; a.cand_ids = L.ids; a.overflow = L.overflow; a.cand_keys = L.keys; a.margin_out = L.margin;
   const int64_t grid = scan_b16_grid(n_rows, col_splits, dp);
   a.lids = reinterpret_cast<uint32_t*>(scratch);
   if (grid_out) *grid_out = (int)grid;

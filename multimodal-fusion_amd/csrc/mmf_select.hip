@@ -22,6 +22,7 @@ struct SelectArgs {
   const float* rx; const float* cy;
   const int32_t* row_ids; int64_t n_rows;
   const uint32_t* cand_cnt; const uint32_t* cand_ids; const uint32_t* overflow; int lists; int cap;
+  const float* cand_keys; const float* margin;      // optional: approximate keys of the entries + the row's error margin
   int64_t* out_idx; float* out_val;
   int32_t* fail_rows; uint32_t* fail_count; uint32_t* cand_total;
   int maxc;   // staged kernel: candidate slots per wave in dynamic LDS
@@ -63,6 +64,71 @@ __device__ __forceinline__ float chain_rows(const void* X, int64_t xr, const voi
   return acc;
 }
 
+// Gather the row's candidate ids from its lists into LDS.  Lists of the 16-bit scan carry the approximate
+// keys G of their entries, and each list was filled against the threshold of ITS columns only.  With several
+// lists per row the union proves a stronger one: if t is the (k + self)-th largest G over all lists, every
+// member of the final top-k has G >= t - margin(row) (same argument as inside the scan), so everything below
+// is dropped here, before any exact chain is spent on it.  (+16 in the ordered-int domain: stored keys carry
+// 4 slot bits.)  key[] is scratch for the approximate keys.  Returns -1 when the candidates do not fit.
+__device__ __forceinline__ int gather_candidates(const SelectArgs& a, int64_t pos, int lane, uint32_t* id, float* key,
+                                                 int maxc) {
+  int total = 0;
+  const bool prune = a.cand_keys != nullptr && a.margin != nullptr;
+  for (int l = 0; l < a.lists; ++l) {
+    const uint32_t cn = a.cand_cnt[pos * a.lists + l];
+    const int64_t base = (pos * a.lists + l) * a.cap;
+    if (total + (int)cn > maxc) return -1;
+    for (uint32_t e = lane; e < cn; e += 64) {
+      id[total + e] = a.cand_ids[base + e];
+      if (prune) key[total + e] = a.cand_keys[base + e];
+    }
+    total += (int)cn;
+  }
+  const int kk = a.k + (a.exclude_self ? 1 : 0);
+  if (!prune || total <= kk) return total;
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  // t = kk-th largest approximate key: kk rounds of "best entry ranked after the previous pick" under
+  // (key desc, position asc), so equal keys are counted once each
+  float pk = 0.0f;
+  uint32_t pe = 0;
+  for (int t = 0; t < kk; ++t) {
+    float bk = kNegInf;
+    uint32_t be = kNoIdx;
+    for (int e = lane; e < total; e += 64) {
+      const float ke = key[e];
+      if (t > 0 && !better(pk, pe, ke, (uint32_t)e)) continue;
+      if (be == kNoIdx || better(ke, (uint32_t)e, bk, be)) { bk = ke; be = (uint32_t)e; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ok = __shfl_xor(bk, o);
+      const uint32_t oe = (uint32_t)__shfl_xor((int)be, o);
+      if (oe != kNoIdx && (be == kNoIdx || better(ok, oe, bk, be))) { bk = ok; be = oe; }
+    }
+    pk = bk; pe = be;
+  }
+  const float thr = pk - a.margin[pos];
+  const int32_t tb = __float_as_int(thr);
+  const int32_t thr_enc = tb >= 0 ? tb : (tb ^ 0x7fffffff);
+  int kept = 0;
+  for (int e0 = 0; e0 < total; e0 += 64) {             // in-place forward compaction (writes never pass reads)
+    const int e = e0 + lane;
+    bool keep = false;
+    uint32_t ie = 0;
+    if (e < total) {
+      const int32_t b = __float_as_int(key[e]);
+      keep = ((b >= 0 ? b : (b ^ 0x7fffffff)) + 16) >= thr_enc;
+      ie = id[e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long mask = __ballot(keep);
+    if (keep) id[kept + __popcll(mask & ((1ull << lane) - 1ull))] = ie;
+    kept += __popcll(mask);
+  }
+  return kept;
+}
+
 template <int METRIC, bool VEC4>
 __global__ __launch_bounds__(64 * SEL_WAVES) void select_kernel(SelectArgs a) {
   __shared__ float skey[SEL_WAVES][SEL_MAXC];
@@ -79,12 +145,8 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_kernel(SelectArgs a) {
   const bool was_overflow = failed;
   int total = 0;
   if (!failed) {
-    for (int l = 0; l < a.lists; ++l) {
-      const uint32_t cn = a.cand_cnt[pos * a.lists + l];
-      if (total + (int)cn > SEL_MAXC) { failed = true; break; }
-      for (uint32_t e = lane; e < cn; e += 64) id[total + e] = a.cand_ids[(pos * a.lists + l) * a.cap + e];
-      total += (int)cn;
-    }
+    total = gather_candidates(a, pos, lane, id, key, SEL_MAXC);
+    if (total < 0) { failed = true; total = 0; }
   }
   const int64_t grow = a.row_offset + row;
   int valid = 0;
@@ -177,12 +239,8 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
   const bool was_overflow = failed;
   int total = 0;
   if (!failed) {
-    for (int l = 0; l < a.lists; ++l) {
-      const uint32_t cn = a.cand_cnt[pos * a.lists + l];
-      if (total + (int)cn > maxc) { failed = true; break; }
-      for (uint32_t e = lane; e < cn; e += 64) id[total + e] = a.cand_ids[(pos * a.lists + l) * a.cap + e];
-      total += (int)cn;
-    }
+    total = gather_candidates(a, pos, lane, id, key, maxc);
+    if (total < 0) { failed = true; total = 0; }
   }
   const int64_t grow = a.row_offset + row;
   int valid = 0;
@@ -323,6 +381,7 @@ int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
   a.row_offset = p.row_offset; a.col_offset = p.col_offset; a.rx = p.rx; a.cy = p.cy;
   a.row_ids = p.row_ids; a.n_rows = p.n_rows;
   a.cand_cnt = L.cnt; a.cand_ids = L.ids; a.overflow = L.overflow; a.lists = L.lists; a.cap = L.cap;
+  a.cand_keys = L.keys; a.margin = L.margin;
   a.out_idx = p.out_idx; a.out_val = p.out_val;
   a.fail_rows = p.fail_rows; a.fail_count = p.fail_count; a.cand_total = p.cand_total;
   const bool v4 = p.dtype == MMF_F32 && (p.d % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0) &&

@@ -12,8 +12,8 @@ Y = make_rows(0, N, d, dev)
 X = Y[: N // P]
 sink = torch.zeros(4, device=dev)
 side = torch.cuda.Stream()
-for wgs, ms in ((0, 0.0), (32, 2.0), (64, 2.0), (32, 6.0)):
-    for splits in (2, 4, 8):
+for wgs, ms in ((0, 0.0), (1, 2.0), (8, 2.0), (32, 0.05), (32, 1.0), (32, 2.0), (32, 4.0)):
+    for splits in (2, 8):
         best = 1e9
         for it in range(4):
             torch.cuda.synchronize(); t0 = time.perf_counter()
