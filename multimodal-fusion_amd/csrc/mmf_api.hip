@@ -142,6 +142,7 @@ struct FastTail {
   char* scan_scratch = nullptr;
 
   int dp, panels;
+  int panel_splits[16]; int max_splits = 1;
   int64_t n_seed;
   int32_t* seed = nullptr;
   // a handful of flagged rows skips the matrix-core rescan: all their keys, then a block-wide top-k
@@ -160,7 +161,26 @@ struct FastTail {
     if (forced_splits > 0) { while (splits < forced_splits) splits <<= 1; }
     else { while (row_blocks * splits < 256 && splits < 32) splits <<= 1; }
     while (splits > 1 && (splits > col_tiles || 2 * splits * panels * bcap > 1024)) splits >>= 1;
-    lists = 2 * splits * panels;
+    // The first half of the panels runs while the rest of the exchange is still on the wire and its kernel
+    // holds compute units.  MMF_PANEL_FRONT_FACTOR = 2 or 4 gives those launches that many times the workgroups
+    // (shorter ones), which shortens the tail the late-joining units leave — measured with a stand-in kernel
+    // (scripts/overlap_sim.py) it trades 0.6 ms without contention for 0.9 ms with it, so the default stays 1.
+    int front = 1;
+    if (const char* e = getenv("MMF_PANEL_FRONT_FACTOR")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) front = v; }
+    int total_splits = 0;
+    for (int p = 0; p < panels && p < 16; ++p) {
+      int sp = splits * ((panels > 1 && p < panels / 2) ? front : 1);
+      while (sp > 1 && sp > col_tiles) sp >>= 1;
+      panel_splits[p] = sp;
+      total_splits += sp;
+    }
+    if (2 * total_splits * bcap > 1024) {            // too many lists for the select kernel: uniform
+      total_splits = splits * panels;
+      for (int p = 0; p < panels && p < 16; ++p) panel_splits[p] = splits;
+    }
+    max_splits = 1;
+    for (int p = 0; p < panels && p < 16; ++p) if (panel_splits[p] > max_splits) max_splits = panel_splits[p];
+    lists = 2 * total_splits;
     rows_exact_cap = (int64_t(64) << 20) / (4 * (m > 0 ? m : 1));
     if (rows_exact_cap > kRowsExactMax) rows_exact_cap = kRowsExactMax;
     if (rows_exact_cap < 1) rows_exact_cap = 1;
@@ -171,7 +191,7 @@ struct FastTail {
   size_t bytes() const {
     return ws_bytes((size_t)n * lists, 4) + 2 * ws_bytes((size_t)n * lists * bcap, 4) + 3 * ws_bytes(n, 4) + ws_bytes(4, 4) +
            ws_bytes(256, 4) + ws_bytes((size_t)FB * fb_lists, 4) + ws_bytes((size_t)FB * fb_lists * cap, 4) +
-           2 * ws_bytes(FB, 4) + ws_bytes(4, 4) + ws_bytes(scan_b16_scratch_bytes(n, splits, dp), 1) + ws_bytes(2 * n_seed, 4) +
+           2 * ws_bytes(FB, 4) + ws_bytes(4, 4) + ws_bytes(scan_b16_scratch_bytes(n, max_splits, dp), 1) + ws_bytes(2 * n_seed, 4) +
            ws_bytes((size_t)rows_exact_cap * m, 4);
   }
   void carve(Workspace& ws) {
@@ -190,7 +210,7 @@ struct FastTail {
     FL.lists = fb_lists; FL.cap = cap;
     fb_fail_rows = ws.take<int32_t>(FB);
     fb_fail_count = ws.take<uint32_t>(4);
-    scan_scratch = ws.take<char>(scan_b16_scratch_bytes(n, splits, dp));
+    scan_scratch = ws.take<char>(scan_b16_scratch_bytes(n, max_splits, dp));
     seed = ws.take<int32_t>(2 * n_seed);
     if (lists <= 2) { L.keys = nullptr; L.margin = nullptr; }    // one list pair per row: nothing to prune against
     row_keys = ws.take<float>((size_t)rows_exact_cap * m);
@@ -214,13 +234,15 @@ struct FastTail {
     } else {
       // one launch per panel, each behind its own arrival event; the launches share the lists (disjoint
       // slots), the id scratch (they run one after the other) and the per-query thresholds
+      int list_base = 0;
       for (int p = 0; p < fo.n_panels; ++p) {
         const mmf_panel& P = fo.panels[p];
         if (P.ready_event) MMF_HIP(hipStreamWaitEvent(s, static_cast<hipEvent_t>(P.ready_event), 0));
-        pn.list_base = 2 * splits * p;
+        pn.list_base = list_base;
+        list_base += 2 * panel_splits[p];
         pn.seg_len = (uint32_t)P.seg_len; pn.seg_stride = (uint32_t)P.seg_stride; pn.id_off = (uint32_t)P.id_base;
         MMF_TRY(launch_scan_b16(fo.ZQ, P.Z, P.cb, fo.q_zn, fo.q_rn, fo.q_un, fo.max_c, n, P.m, P.m_pad, fo.dp, d, fo.f16,
-                                metric, kk, splits, L, scan_scratch, pn, s, &grid));
+                                metric, kk, panel_splits[p], L, scan_scratch, pn, s, &grid));
       }
     }
     MMF_TRY(launch_scan_b16_audit(pn, L.overflow, n, s));

@@ -9,13 +9,22 @@ from bench import make_rows
 dev = torch.device('cuda')
 N, d = 262144, 512
 CH = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+OCC_WGS = int(sys.argv[2]) if len(sys.argv) > 2 else 0        # stand-in for the collectives' kernel (scripts/occupy)
+OCC_MS = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+import ctypes
+occ = None
+if OCC_WGS:
+    occ = ctypes.CDLL("scripts/occupy/liboccupy.so")
+    occ.occupy_launch.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+    sink = torch.zeros(4, device='cuda')
+    occ_stream = torch.cuda.Stream()
 Y = make_rows(0, N, d, dev)
 ref_i, ref_v = mmf.simtopk(Y, metric='cosine', k=5)
 
 class FakeWork:
     def wait(self): pass
 
-for P in (2, 4, 8):
+for P in ((8,) if OCC_WGS else (2, 4, 8)):
     rank = P - 1
     lo, hi = dmod.shard_bounds(N, P, rank)
     store = {}
@@ -54,10 +63,12 @@ for P in (2, 4, 8):
     for it in range(6):
         calls["i"] = 0
         torch.cuda.synchronize(); t0 = time.perf_counter()
+        if occ is not None:
+            occ.occupy_launch(OCC_WGS, OCC_MS, sink.data_ptr(), occ_stream.cuda_stream)
         i, v, st = dmod._overlapped_simtopk(xl, N, lo, hi, P, metric="cosine", lam=1.0, k=5, exclude_self=True, chunks=CH,
                                             operand="f16", group=None, return_stats=True)
         t1 = time.perf_counter()
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
     ok = torch.equal(i, ref_i[lo:hi]) and torch.equal(v, ref_v[lo:hi])
-    print("chunks=%d " % CH + "P=%d rank=%d rows=%d: wall=%.2f ms (host enqueue %.2f) scan=%.2f prep=%.2f rerank=%.2f fb=%d (overflow %d short %d) cand/row=%.1f parity=%s" % (
+    print("chunks=%d occ=%dx%.1fms front=%s " % (CH, OCC_WGS, OCC_MS, __import__("os").environ.get("MMF_PANEL_FRONT_FACTOR", "2")) + "P=%d rank=%d rows=%d: wall=%.2f ms (host enqueue %.2f) scan=%.2f prep=%.2f rerank=%.2f fb=%d (overflow %d short %d) cand/row=%.1f parity=%s" % (
         P, rank, hi - lo, dt, (t1 - t0) * 1e3, st['scan_ms'], st['prep_ms'], st['rerank_ms'], st['fallback_rows'], st['overflow_rows'], st['short_rows'], st['candidates'] / (hi - lo), ok), flush=True)
