@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libmmf_hg.so")
+SO_PATH = os.environ.get("MMF_HG_LIBRARY") or os.path.join(_HERE, "libmmf_hg.so")   # override: a library built elsewhere
 
 MMF_OK, MMF_E_INVALID, MMF_E_UNSUPPORTED, MMF_E_HIP, MMF_E_NOMEM, MMF_E_INTERNAL = 0, -1, -2, -3, -4, -5
 DOT, COSINE, NEG_SQ_L2, RBF, RBF_DIRECT = 0, 1, 2, 3, 4

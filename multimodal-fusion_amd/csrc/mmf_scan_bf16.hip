@@ -190,9 +190,16 @@ __device__ __forceinline__ int32_t seed_enc(float f) {
 }
 constexpr int32_t kSeedNone = (int32_t)0x80808080;   // hipMemset(0x80) pattern: "no threshold yet"
 
-#define MMF_GLDS(gptr, lptr, size) \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), \
-                                   (__attribute__((address_space(3))) void*)(lptr), size, 0, 0)
+// LDS-DMA (global -> LDS, no registers).  LDS address = wave-uniform base + lane * size.
+// (Tried: the same instruction as inline asm, hidden from the compiler's waitcnt scoreboard — it models the
+// builtin as a FLAT access and degrades the waits inside the MFMA chain to lgkmcnt(0).  The counted waits that
+// buys measured 0.8 % SLOWER on the same box; two waves per SIMD already cover those stalls.)
+__device__ __forceinline__ void glds16(const void* gptr, const void* lptr) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const void* gptr, const void* lptr) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 4, 0, 0);
+}
 
 // NW waves per workgroup (32 queries each), TPB tiles per barrier (2 * TPB tile stages in LDS):
 //   d <= 512 : NW = 8 (two waves per SIMD, 256 VGPRs each), TPB = 2
@@ -322,12 +329,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(Sc
   const char* zc0 = reinterpret_cast<const char*>(a.ZC) + t_begin * (int64_t)TILEB;          // tile 0 of my range
   const char* cb0 = reinterpret_cast<const char*>(a.cb + t_begin * B_CT);
   auto issue_piece = [&](const char* tsrc, int stage, int i) {
-    MMF_GLDS(tsrc + src_off[i], tiles + stage * TILEB + (wave + NW * i) * 1024, 16);
+    glds16(tsrc + src_off[i], tiles + stage * TILEB + (wave + NW * i) * 1024);
   };
   // the 32 biases of a tile: one 4-byte DMA by lanes 0..31 of the wave whose turn it is
   auto issue_bias = [&](const char* bsrc, int stage) {
     const uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // lane id, no live VGPR
-    if (l < 32) MMF_GLDS(bsrc + l * 4u, cbs + stage * 64, 4);
+    if (l < 32) glds4(bsrc + l * 4u, cbs + stage * 64);
   };
 
   const int Ti = (int)T;
