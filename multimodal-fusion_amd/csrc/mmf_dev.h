@@ -492,12 +492,18 @@ struct SlotList {
     }
   }
 
-  // warm lists: one compaction site, then 16 straight-line tests; a hit that still finds its list full
+  // warm lists: one compaction site, then the rows that hold a hit; a hit that still finds its list full
   // is dropped under the audited-loss rule
   __device__ __forceinline__ void offer_tile_warm(const f32x16& v, uint32_t id0, int half, int kk, float margin) {
     if (__any(cnt >= CAP - 1)) compact(kk, margin);
+    // which of the 16 accumulator rows hold a hit in ANY lane: 16 branch-free compares, then only those rows
+    // (typically one) run the push code — thr only rises meanwhile, so the mask is a superset
+    uint32_t rmask = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 16; ++r) rmask |= (__any(v[r] >= thr) ? 1u : 0u) << r;
+    while (rmask) {
+      const int r = __builtin_ctz(rmask);
+      rmask &= rmask - 1;
       const float x = v[r];
       if (x >= thr) {
         if (cnt < CAP) {

@@ -190,13 +190,7 @@ __device__ __forceinline__ int32_t seed_enc(float f) {
 }
 constexpr int32_t kSeedNone = (int32_t)0x80808080;   // hipMemset(0x80) pattern: "no threshold yet"
 
-// LDS-DMA (global -> LDS, no registers).  LDS address = wave-uniform base + lane * size.
-// (Tried: the same instruction as inline asm, hidden from the compiler's waitcnt scoreboard — it models the
-// builtin as a FLAT access and degrades the waits inside the MFMA chain to lgkmcnt(0).  The counted waits that
-// buys measured 0.8 % SLOWER on the same box; two waves per SIMD already cover those stalls.)
-__device__ __forceinline__ void glds16(const void* gptr, const void* lptr) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0);
-}
+// LDS-DMA (global -> LDS, no registers) of the 32 biases of a tile.  LDS address = wave-uniform base + lane * 4.
 __device__ __forceinline__ void glds4(const void* gptr, const void* lptr) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 4, 0, 0);
 }
@@ -328,8 +322,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(Sc
   }
   const char* zc0 = reinterpret_cast<const char*>(a.ZC) + t_begin * (int64_t)TILEB;          // tile 0 of my range
   const char* cb0 = reinterpret_cast<const char*>(a.cb + t_begin * B_CT);
+  // Tile pieces go through the buffer form of the LDS-DMA: the workgroup's column range is one raw buffer
+  // (base = its first tile), the running tile position is the scalar offset and the lane's swizzled position
+  // the vector offset — no per-piece 64-bit address arithmetic in the MFMA chain, and (unlike the FLAT-encoded
+  // global form) it leaves the compiler's counted lgkmcnt waits for the A-fragment ring intact.
+  const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(zc0), 0, -1, 0x00020000);
   auto issue_piece = [&](const char* tsrc, int stage, int i) {
-    glds16(tsrc + src_off[i], tiles + stage * TILEB + (wave + NW * i) * 1024);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(zrsrc, (__attribute__((address_space(3))) void*)(tiles + stage * TILEB + (wave + NW * i) * 1024),
+                                             16, (int)src_off[i], (int)(uint32_t)(tsrc - zc0), 0, 0);
   };
   // the 32 biases of a tile: one 4-byte DMA by lanes 0..31 of the wave whose turn it is
   auto issue_bias = [&](const char* bsrc, int stage) {
@@ -347,20 +347,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(Sc
       if (wave == (u & (NW - 1))) issue_bias(real ? cb0 + u * B_CT * 4 : cb0, u);
     }
   }
-  // The two waves that share a SIMD (w and w+4) run in lockstep after every barrier.  Issuing the
-  // tile DMA inside the MFMA chain, at different points for the two, lets one wave's VMEM issue sit
-  // under the other's matrix work instead of both stalling the pipe right after the barrier.
-  // The chain itself is straight-line code: two copies of the tile body (lower / upper wave group),
-  // and the DMA of tile t+2 is unconditional — past the end of the range it re-fetches tile 0 into a
-  // stage nobody reads again — so no branch and no per-tile bookkeeping sits between the MFMAs.
-  const bool upper = wave >= NW / 2;
+  // The DMA pieces of tile t+TPB are issued inside the MFMA chain of tile t, one per group of GRP MFMAs.  The
+  // chain is straight-line code and the DMA is unconditional — past the end of the range it re-fetches tile 0
+  // into a stage nobody reads again — so no branch and no per-tile bookkeeping sits between the MFMAs.
+  // (Issuing at different points of the chain for the two waves that share a SIMD used to pay when a piece cost
+  // 64-bit address arithmetic; with the buffer form it measures 0.8 % slower than issuing at the same point.)
   constexpr int GRP = KS / PPW;                      // MFMAs between two DMA pieces
   const char* tsrc = zc0 + TPB * (int64_t)TILEB;     // source of the first tile of the NEXT group
   const char* bsrc = cb0 + TPB * B_CT * 4;
   const uint32_t id_base = (uint32_t)(t_begin * B_CT);
 
-  auto tile_body = [&](auto up_tag, const char* tb, const float* cbt, const char* src, int s2) -> f32x16 {
-    constexpr bool UP = decltype(up_tag)::value;
+  auto tile_body = [&](const char* tb, const float* cbt, const char* src, int s2) -> f32x16 {
     f32x16 acc;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -382,10 +379,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(Sc
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, cur), __builtin_bit_cast(f16x8_t, qf[s]), acc, 0, 0, 0);
       else
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, cur), __builtin_bit_cast(bf16x8_t, qf[s]), acc, 0, 0, 0);
-      // one DMA piece of tile t+2 per group of GRP MFMAs: lower waves at the end of the group,
-      // upper waves in its middle
-      constexpr int at = UP ? ((GRP >= 2) ? GRP / 2 - 1 : 0) : GRP - 1;
-      if ((s % GRP) == at) issue_piece(src, s2, s / GRP);
+      // one DMA piece of tile t+TPB per group of GRP MFMAs
+      if ((s % GRP) == GRP - 1) issue_piece(src, s2, s / GRP);
       // pin the interleave: one LDS read (for step s+PD), then one MFMA (step s); hipcc otherwise
       // falls back to read -> lgkmcnt(0) -> use pairs to save registers
       if (s + PD < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -397,8 +392,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(Sc
   // The filter of tile t-1 runs AFTER barrier t, ahead of this wave's own MFMA chain: a wave that
   // falls into the (rare) list code then delays only itself while its SIMD partner issues MFMAs;
   // placed before the barrier it would hold all eight waves, and their matrix pipes, at the barrier.
-  auto filter = [&](const f32x16& acc, int tt) {
-    const float mx = max16(acc);
+  auto filter = [&](const f32x16& acc, int tt, float mx) {
     if (!(DBG && (a.debug & 1)) && __any(mx >= list.thr)) {
       const uint32_t id0 = id_base + (uint32_t)tt * B_CT;
       // robust (never dropping) path while thresholds are still forming: first 32 tiles of the range
@@ -440,6 +434,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(Sc
   unsigned long long tw = 0, tf = 0, tc = 0, t0s = 0, t1s = 0, t2s = 0, t3s = 0;
   const bool stamps = DBG && (a.debug & 16) != 0;
   f32x16 acc_prev;
+  float mx_prev = kNegInf;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc_prev[r] = kNegInf;      // "tile -1": nothing can hit
   const int nIter = (Ti + TPB - 1) / TPB;
@@ -451,7 +446,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(Sc
     asm volatile("" ::: "memory");
     if (stamps) t1s = __builtin_amdgcn_s_memtime();
 
-    filter(acc_prev, j * TPB - 1);  // behind the barrier: only this wave waits for its own list code
+    filter(acc_prev, j * TPB - 1, mx_prev);  // behind the barrier: only this wave waits for its own list code
     if (stamps) t2s = __builtin_amdgcn_s_memtime();
 
     const int sg = (j & 1) * TPB, ng = TPB - sg;      // stage group read / filled by this iteration
@@ -461,17 +456,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(Sc
       const bool more = (t + TPB < Ti);
       const char* src = more ? tsrc + u * (int64_t)TILEB : zc0;
       f32x16 acc;
-      if (upper) acc = tile_body(std::true_type{}, tiles + (sg + u) * TILEB, cbs + (sg + u) * 64, src, ng + u);
-      else acc = tile_body(std::false_type{}, tiles + (sg + u) * TILEB, cbs + (sg + u) * 64, src, ng + u);
+      acc = tile_body(tiles + (sg + u) * TILEB, cbs + (sg + u) * 64, src, ng + u);
       if (wave == ((t + TPB) & (NW - 1))) issue_bias(more ? bsrc + u * B_CT * 4 : cb0, ng + u);
       if (u < TPB - 1) {
-        filter(acc, t);             // mid-iteration, no barrier nearby
+        filter(acc, t, max16(acc));   // mid-iteration, no barrier nearby
       } else {
         if (t >= Ti) {              // ragged range: the last tile of the last group is a dummy
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = kNegInf;
         }
         acc_prev = acc;
+        mx_prev = max16(acc);         // reduced BEFORE the barrier, in time this wave would otherwise spend waiting
       }
     }
     tsrc += TPB * (int64_t)TILEB;
@@ -485,7 +480,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(Sc
   if (stamps && lane == 0) {
     atomicAdd(a.dbg + 0, tw); atomicAdd(a.dbg + 1, tf); atomicAdd(a.dbg + 2, tc); atomicAdd(a.dbg + 3, (unsigned long long)Ti);
   }
-  if (Ti > 0) filter(acc_prev, nIter * TPB - 1);
+  if (Ti > 0) filter(acc_prev, nIter * TPB - 1, max16(acc_prev));
   __builtin_amdgcn_s_waitcnt(0x0F70);   // the dummy tiles still in flight
 
   list.compact(a.kk, margin);
@@ -607,6 +602,11 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
   a.ZQ = ZQ; a.ZC = ZC; a.cb = cb; a.q_zn = q_zn; a.q_rn = q_rn; a.q_un = q_un; a.maxima = maxima;
   a.n_rows = n_rows; a.m = m; a.tiles_total = m_pad / B_CT;
   a.tiles_per_split = (a.tiles_total + col_splits - 1) / col_splits;
+  if (a.tiles_per_split * (int64_t)B_CT * dp * 2 >= (int64_t(1) << 32)) {   // 32-bit scalar offsets of the tile DMA
+    set_error("scan_b16: a column range of %lld tiles x %d exceeds 4 GiB of operands; use more col_splits",
+              (long long)a.tiles_per_split, dp);
+    return MMF_E_UNSUPPORTED;
+  }
   a.row_blocks = (n_rows + scan_b16_queries_per_block(dp) - 1) / scan_b16_queries_per_block(dp);
   a.col_splits = col_splits; a.kk = kk; a.metric = metric; a.d = (int)d;
   a.conc_splits = conc_splits_for(a.row_blocks, col_splits);
