@@ -77,3 +77,27 @@ def test_shard_bounds_partition():
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_chunk_layout_of_the_pipelined_exchange_maps_back_to_global_columns():
+    """The pipelined driver all-gathers chunk c = rows [c*rows/S, (c+1)*rows/S) of every rank; rank-major
+    concatenation makes column i of that panel global column id_base + (i // seg_len) * seg_stride + i % seg_len
+    (include/mmf_hg.h, mmf_panel).  Check the formula against an explicit gather, and that the panels tile [0, N)."""
+    import importlib
+    dmod = importlib.import_module("multimodal_fusion_amd.distributed")
+    for world, rows, S in ((8, 64, 4), (4, 30, 2), (3, 7, 1), (2, 12, 3)):
+        n = world * rows
+        seg = rows // S
+        owner_rows = [np.arange(*dmod.shard_bounds(n, world, r)) for r in range(world)]
+        seen = []
+        for c in range(S):
+            gathered = np.concatenate([owner_rows[r][c * seg:(c + 1) * seg] for r in range(world)])   # all_gather_into_tensor
+            i = np.arange(world * seg)
+            mapped = c * seg + (i // seg) * rows + i % seg
+            assert np.array_equal(mapped, gathered), (world, rows, S, c)
+            seen.append(mapped)
+        assert np.array_equal(np.sort(np.concatenate(seen)), np.arange(n))
+    assert dmod._pick_chunks(32768, 8, None) == 4 and dmod._pick_chunks(1000, 2, None) == 1
+    assert dmod._pick_chunks(32768, 8, 2) == 2
+    with pytest.raises(ValueError):
+        dmod._pick_chunks(1000, 2, 3)
