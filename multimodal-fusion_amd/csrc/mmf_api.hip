@@ -270,6 +270,19 @@ struct FastTail {
     if (stats) MMF_HIP(hipMemcpyAsync(h_tot.data(), cand_total, 1024, hipMemcpyDeviceToHost, s));
     MMF_HIP(hipStreamSynchronize(s));
     const uint32_t h_fail = h_fail4[0];
+    if (h_fail > 0 && getenv("MMF_DEBUG_PRINT_FLAGGED")) {   // diagnosis: which rows, and the threshold / dropped key that flagged them
+      const uint32_t nshow = h_fail < 8 ? h_fail : 8;
+      int32_t rows[8];
+      MMF_HIP(hipMemcpy(rows, fail_rows, nshow * sizeof(int32_t), hipMemcpyDeviceToHost));
+      for (uint32_t i = 0; i < nshow; ++i) {
+        int32_t enc[2] = {0, 0};
+        MMF_HIP(hipMemcpy(&enc[0], seed + rows[i], 4, hipMemcpyDeviceToHost));
+        MMF_HIP(hipMemcpy(&enc[1], seed + n_seed + rows[i], 4, hipMemcpyDeviceToHost));
+        auto dec = [](int32_t o) { int32_t b = o >= 0 ? o : (o ^ 0x7fffffff); float f; memcpy(&f, &b, 4); return f; };
+        fprintf(stderr, "[mmf flagged] row %d: best threshold %.9g (enc %d)  best dropped key %.9g (enc %d)  overflow %u short %u\n",
+                rows[i], dec(enc[0]), enc[0], dec(enc[1]), enc[1], h_fail4[1], h_fail4[2]);
+      }
+    }
 
     MMF_TRY(t_fb.start(profile && h_fail > 0, s));
     if (h_fail > 0 && (int64_t)h_fail <= kRowsExactMax) {

@@ -473,31 +473,14 @@ struct SlotList {
     cnt = w;
   }
 
-  // robust path (cold start): never drops, compacts whenever a list fills
-  __device__ __forceinline__ void offer_tile_cold(const f32x16& v, uint32_t id0, int half, int kk, float margin) {
-#pragma unroll 1
-    for (int r = 0; r < 16; ++r) {
-      const float x = v[r];
-      bool hit = x >= thr;
-      if (__any(hit)) {
-        if (__any(hit && cnt >= CAP)) {
-          compact(kk, margin);
-          hit = x >= thr;
-        }
-        if (hit) {
-          if (cnt < CAP) push(x, id0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * half));
-          else { lost = fmaxf(lost, x); thr = fmaxf(thr, lost); }
-        }
-      }
-    }
-  }
-
-  // warm lists: one compaction site, then the rows that hold a hit; a hit that still finds its list full
-  // is dropped under the audited-loss rule
-  __device__ __forceinline__ void offer_tile_warm(const f32x16& v, uint32_t id0, int half, int kk, float margin) {
+  // One tile's 16 values of this lane's query.  rowof(r): tile row (0..31) of element r — the MFMA shape's C layout.
+  // A pre-emptive compaction when some list is nearly full, then only the accumulator rows that hold a hit in
+  // ANY lane run the push code (16 branch-free compares find them; thr only rises meanwhile, so the mask is a
+  // superset).  A hit that finds its list full compacts first (wave-wide; the loop is wave-uniform) and is
+  // dropped — under the audited-loss rule — only if that frees nothing.
+  template <class RowOf>
+  __device__ __forceinline__ void offer_tile(const f32x16& v, uint32_t id0, RowOf rowof, int kk, float margin) {
     if (__any(cnt >= CAP - 1)) compact(kk, margin);
-    // which of the 16 accumulator rows hold a hit in ANY lane: 16 branch-free compares, then only those rows
-    // (typically one) run the push code — thr only rises meanwhile, so the mask is a superset
     uint32_t rmask = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) rmask |= (__any(v[r] >= thr) ? 1u : 0u) << r;
@@ -505,9 +488,14 @@ struct SlotList {
       const int r = __builtin_ctz(rmask);
       rmask &= rmask - 1;
       const float x = v[r];
-      if (x >= thr) {
+      bool hit = x >= thr;
+      if (__any(hit && cnt >= CAP)) {
+        compact(kk, margin);
+        hit = x >= thr;
+      }
+      if (hit) {
         if (cnt < CAP) {
-          push(x, id0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * half));
+          push(x, id0 + rowof(r));
         } else {
           lost = fmaxf(lost, x);
           thr = fmaxf(thr, lost);
@@ -515,6 +503,12 @@ struct SlotList {
       }
     }
   }
+};
+
+// C layout of v_mfma_f32_32x32x*: lane (column, half = lane >> 5), element r -> row
+struct RowOf32 {
+  int half;
+  __device__ __forceinline__ uint32_t operator()(int r) const { return (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * half); }
 };
 
 __device__ __forceinline__ float max16(const f32x16& v) {
