@@ -26,8 +26,9 @@ namespace mmf {
 constexpr int F_NT = 256;
 constexpr int F_QT = 128;
 constexpr int F_CT = 128;
-constexpr int F_KC = 32;
-constexpr int F_LD = 33;
+// k per staged chunk (template parameter KC, row stride KC + 1 floats): 16 for the scan — 2 x (128 + 128) rows x 17
+// floats = 35 KB beside 32 KB of lists, so two workgroups share a CU — and 32 for the dense outputs (no lists: two
+// workgroups fit anyway, and half the barriers measure 7 % faster).
 
 constexpr int MODE_SCAN = 0;
 constexpr int MODE_DENSE = 1;
@@ -63,8 +64,12 @@ __device__ __forceinline__ f32x4 load4(const void* base, int64_t row, int64_t k,
   return v;
 }
 
-template <int MODE, int CAP, bool VEC4>
-__global__ __launch_bounds__(F_NT) void scan_f32_kernel(ScanF32Args a) {
+template <int MODE, int CAP, bool VEC4, int F_KC>
+__global__ __launch_bounds__(F_NT, (MODE == MODE_DENSE || CAP <= 16) ? 2 : 1) void scan_f32_kernel(ScanF32Args a) {
+  constexpr int F_LD = F_KC + 1;
+  constexpr int TPR = F_KC / 4;          // staging: threads per row (16 bytes each)
+  constexpr int RPP = F_NT / TPR;        //          rows per pass
+  constexpr int NP = F_QT / RPP;         //          passes per 128-row tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* Qs = reinterpret_cast<float*>(smem);   // [2][F_QT][F_LD]
   float* Cs = Qs + 2 * F_QT * F_LD;             // [2][F_CT][F_LD]
@@ -97,24 +102,34 @@ __global__ __launch_bounds__(F_NT) void scan_f32_kernel(ScanF32Args a) {
   const float ri = qvalid ? a.rx[qrow] : 1.0f;
   const int metric = a.metric;
 
+  // DENSE: the 16 query rows this lane's accumulator elements belong to (fixed for the workgroup's lifetime)
+  float rq16[16];
+  if constexpr (MODE == MODE_DENSE) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t q = q0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half;
+      rq16[r] = (q < a.n_rows) ? a.rx[q] : 1.0f;
+    }
+  }
+
   LaneList<CAP, F_NT> list;
   if constexpr (MODE == MODE_SCAN) {
     list.init(lkeys + tid, lids + tid);
     if (!qvalid) list.thr = __builtin_huge_valf();
   }
 
-  // staging roles: rows (tid>>3) + 32*i, k offset 4*(tid&7)
-  const int srow = tid >> 3;
-  const int sk = 4 * (tid & 7);
-  int64_t qsrc[4];
+  // staging roles: rows (tid / TPR) + RPP*i, k offset 4*(tid % TPR)
+  const int srow = tid / TPR;
+  const int sk = 4 * (tid % TPR);
+  int64_t qsrc[NP];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int64_t p = q0 + srow + 32 * i;
+  for (int i = 0; i < NP; ++i) {
+    int64_t p = q0 + srow + RPP * i;
     if (p > a.n_rows - 1) p = a.n_rows - 1;
     qsrc[i] = a.row_ids ? (int64_t)a.row_ids[p] : p;
   }
 
-  f32x4 rq[4], rc[4];
+  f32x4 rq[NP], rc[NP];
   float rcy = 0.0f;
   auto gload = [&](int64_t step) {
     const int64_t ct = t_begin + step / nkc;
@@ -129,17 +144,17 @@ __global__ __launch_bounds__(F_NT) void scan_f32_kernel(ScanF32Args a) {
       const float* xf = reinterpret_cast<const float*>(a.X);
       const float* yf = reinterpret_cast<const float*>(a.Y);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NP; ++i) {
         rq[i] = *reinterpret_cast<const f32x4*>(xf + qsrc[i] * a.d + k);
-        int64_t j = ct * F_CT + srow + 32 * i;
+        int64_t j = ct * F_CT + srow + RPP * i;
         if (j > a.m - 1) j = a.m - 1;
         rc[i] = *reinterpret_cast<const f32x4*>(yf + j * a.d + k);
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NP; ++i) {
         rq[i] = load4<VEC4>(a.X, qsrc[i], k, a.d, a.dtype);
-        int64_t j = ct * F_CT + srow + 32 * i;
+        int64_t j = ct * F_CT + srow + RPP * i;
         if (j > a.m - 1) j = a.m - 1;
         rc[i] = load4<VEC4>(a.Y, j, k, a.d, a.dtype);
       }
@@ -150,11 +165,11 @@ __global__ __launch_bounds__(F_NT) void scan_f32_kernel(ScanF32Args a) {
     float* qd = Qs + buf * F_QT * F_LD + srow * F_LD + sk;
     float* cd = Cs + buf * F_CT * F_LD + srow * F_LD + sk;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NP; ++i) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        qd[i * 32 * F_LD + e] = rq[i][e];
-        cd[i * 32 * F_LD + e] = rc[i][e];
+        qd[i * RPP * F_LD + e] = rq[i][e];
+        cd[i * RPP * F_LD + e] = rc[i][e];
       }
     }
   };
@@ -195,7 +210,13 @@ __global__ __launch_bounds__(F_NT) void scan_f32_kernel(ScanF32Args a) {
         for (int t = 0; t < 4; ++t) avn[t] = Cb[t * 32 * F_LD + 2 * (k2 + 1)];
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], b, acc[t], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) {
+        // SCAN: C rows = candidates, columns = queries (a lane owns one query).  DENSE: the transpose — a lane owns
+        // one candidate COLUMN of the output, so the 32 lanes of a half store 128 contiguous bytes of one output
+        // row.  Products commute, the k order is the same: both orientations give the same bits.
+        if constexpr (MODE == MODE_DENSE) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, av[t], acc[t], 0, 0, 0);
+        else acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], b, acc[t], 0, 0, 0);
+      }
       if (k2 + 1 < F_KC / 2) __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     }
@@ -204,6 +225,40 @@ __global__ __launch_bounds__(F_NT) void scan_f32_kernel(ScanF32Args a) {
       const int64_t ct = t_begin + s / nkc;
       // one 32 x 32 sub-tile at a time (keeping all four key vectors live costs 64 VGPRs and pushes the
       // staging registers of the next chunk into AGPRs, i.e. a vmcnt(0) in front of the MFMA block)
+      if constexpr (MODE == MODE_DENSE) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int64_t j = ct * F_CT + 32 * t + c;            // this lane's output column
+          const bool jv = j < a.m;
+          const float cj = cys[((s / nkc) & 1) * F_CT + 32 * t + c];
+          const float nl = (metric == MMF_RBF) ? a.neg_lambda : -1.0f;  // (-1)*sq == -sq exactly
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t q = q0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float dot = acc[t][r];
+            acc[t][r] = 0.0f;
+            if (jv && q < a.n_rows) {
+              float key;
+              if (metric == MMF_DOT) key = dot;
+              else if (metric == MMF_COSINE) key = key_from_dot<MMF_COSINE>(dot, rq16[r], cj, 0.0f);
+              else key = key_from_dot<MMF_RBF>(dot, rq16[r], cj, nl);
+              float v = (metric == MMF_RBF) ? expf(key) : key;
+              if (a.P) {
+                // K_g from the positions, canonical chains over dp (similarity_kernel.py:79-84, 122)
+                float ni = 0.f, nj = 0.f, dp_ = 0.f;
+                for (int e = 0; e < a.dp; ++e) {
+                  const float pi = a.P[q * a.dp + e], pj = a.P[j * a.dp + e];
+                  ni = __builtin_fmaf(pi, pi, ni);
+                  nj = __builtin_fmaf(pj, pj, nj);
+                  dp_ = __builtin_fmaf(pi, pj, dp_);
+                }
+                v = v * expf(a.neg_lambda_g * sq_from(ni, nj, dp_));
+              }
+              a.out[q * a.m + j] = v;
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int64_t cand0 = ct * F_CT + 32 * t;
@@ -235,36 +290,11 @@ __global__ __launch_bounds__(F_NT) void scan_f32_kernel(ScanF32Args a) {
           key[r] = jv ? key[r] : kNegInf;
           acc[t][r] = 0.0f;
         }
-        if constexpr (MODE == MODE_SCAN) {
-          if (__any(max16(key) >= list.thr)) list.template offer_tile<true>(key, (uint32_t)cand0, half, a.kk, 0.0f);
-        } else {
-          if (qvalid) {
-            float* orow = a.out + qrow * a.m;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int64_t j = cand0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-              if (j < a.m) {
-                float v = (metric == MMF_RBF) ? expf(key[r]) : key[r];
-                if (a.P) {
-                  // K_g from the positions, canonical chains over dp (similarity_kernel.py:79-84, 122)
-                  float ni = 0.f, nj = 0.f, dp_ = 0.f;
-                  for (int e = 0; e < a.dp; ++e) {
-                    const float pi = a.P[qrow * a.dp + e], pj = a.P[j * a.dp + e];
-                    ni = __builtin_fmaf(pi, pi, ni);
-                    nj = __builtin_fmaf(pj, pj, nj);
-                    dp_ = __builtin_fmaf(pi, pj, dp_);
-                  }
-                  const float kg = expf(a.neg_lambda_g * sq_from(ni, nj, dp_));
-                  v = v * kg;
-                }
-                orow[j] = v;
-              }
-            }
-          }
-        }
+        if (__any(max16(key) >= list.thr)) list.template offer_tile<true>(key, (uint32_t)cand0, half, a.kk, 0.0f);
       }
     }
 
+      }
     if (s + 1 < steps && !(a.debug & 2)) swrite(buf ^ 1, s + 1);
     __syncthreads();
   }
@@ -323,8 +353,8 @@ int scan_f32_cap(int kk) {
   return 0;
 }
 
-static size_t scan_f32_lds(int cap) {
-  return sizeof(float) * (2 * F_QT * F_LD + 2 * F_CT * F_LD + 2 * F_CT) + (size_t)cap * F_NT * 8;
+static size_t scan_f32_lds(int cap, int kc) {
+  return sizeof(float) * (2 * F_QT * (kc + 1) + 2 * F_CT * (kc + 1) + 2 * F_CT) + (size_t)cap * F_NT * 8;
 }
 
 template <int MODE, int CAP>
@@ -333,15 +363,16 @@ static int launch_f32_t(const ScanF32Args& a, bool vec4, int64_t grid, hipStream
     set_error("scan_f32: unsupported metric %d", a.metric);
     return MMF_E_INVALID;
   }
-  const size_t lds = scan_f32_lds(MODE == MODE_SCAN ? CAP : 0);
+  constexpr int KC = (MODE == MODE_SCAN) ? 16 : 32;
+  const size_t lds = scan_f32_lds(MODE == MODE_SCAN ? CAP : 0, KC);
   auto go = [&](auto kern) -> int {
     MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(F_NT), lds, s, a);
     MMF_LAUNCH_CHECK();
     return MMF_OK;
   };
-  if (vec4) return go(scan_f32_kernel<MODE, CAP, true>);
-  return go(scan_f32_kernel<MODE, CAP, false>);
+  if (vec4) return go(scan_f32_kernel<MODE, CAP, true, KC>);
+  return go(scan_f32_kernel<MODE, CAP, false, KC>);
 }
 
 static bool can_vec4(const void* X, const void* Y, int64_t d, int dtype) {
@@ -369,9 +400,65 @@ int launch_scan_f32(const ScanProblem& p, const CandLists& L, hipStream_t s, int
   return MMF_E_INTERNAL;
 }
 
+// d <= 8 (the spatial similarity of similarity_kernel.py:58-86 has d = 2): no matrix cores, the kernel is pure
+// output bandwidth.  A thread owns 4 consecutive output columns (its 4 y vectors stay in registers) and walks 16
+// rows; each store is 16 bytes per lane, 1 KiB contiguous per wave.  Same canonical chains and keys as everywhere.
+__global__ __launch_bounds__(256) void dense_small_d_kernel(const void* __restrict__ X, int64_t n, const void* __restrict__ Y,
+                                                            int64_t m, int d, int dtype, int metric, float neg_lambda,
+                                                            const float* __restrict__ rx, const float* __restrict__ cy,
+                                                            float* __restrict__ out) {
+  const int64_t j0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int64_t i0 = (int64_t)blockIdx.y * 16;
+  if (j0 >= m) return;
+  float y[4][8], cj[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int64_t j = (j0 + jj < m) ? (j0 + jj) : (m - 1);
+    cj[jj] = cy[j];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) y[jj][k] = (k < d) ? ld_elem(Y, j * d + k, dtype) : 0.0f;
+  }
+  const float nl = (metric == MMF_RBF) ? neg_lambda : -1.0f;
+  const bool vec = ((m & 3) == 0) && (j0 + 3 < m) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  for (int ii = 0; ii < 16; ++ii) {
+    const int64_t i = i0 + ii;
+    if (i >= n) break;
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = (k < d) ? ld_elem(X, i * d + k, dtype) : 0.0f;
+    const float ri = rx[i];
+    f32x4 v;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      float dot = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < d) dot = __builtin_fmaf(x[k], y[jj][k], dot);
+      float key;
+      if (metric == MMF_DOT) key = dot;
+      else if (metric == MMF_COSINE) key = key_from_dot<MMF_COSINE>(dot, ri, cj[jj], 0.0f);
+      else key = key_from_dot<MMF_RBF>(dot, ri, cj[jj], nl);
+      v[jj] = (metric == MMF_RBF) ? expf(key) : key;
+    }
+    float* o = out + i * m + j0;
+    if (vec) *reinterpret_cast<f32x4*>(o) = v;
+    else {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        if (j0 + jj < m) o[jj] = v[jj];
+    }
+  }
+}
+
 int launch_sim_dense(const void* X, int64_t n, const void* Y, int64_t m, int64_t d, int dtype, int metric,
                      float lambda, const float* rx, const float* cy, float* out, hipStream_t s) {
   if (n <= 0 || m <= 0) return MMF_OK;
+  if (d <= 8 && metric != MMF_RBF_DIRECT) {
+    dim3 grid((unsigned)((m + 1023) / 1024), (unsigned)((n + 15) / 16));
+    hipLaunchKernelGGL(dense_small_d_kernel, grid, dim3(256), 0, s, X, n, Y, m, (int)d, dtype, metric, -lambda, rx, cy, out);
+    MMF_LAUNCH_CHECK();
+    return MMF_OK;
+  }
   if (metric == MMF_RBF_DIRECT) {
     dim3 grid((unsigned)((m + 31) / 32), (unsigned)((n + 31) / 32));
     hipLaunchKernelGGL(rbf_direct_kernel, grid, dim3(256), 0, s, X, n, Y, m, d, dtype, -lambda, out);
