@@ -32,6 +32,10 @@ __global__ void median_init_kernel(MedianState* st, unsigned long long rank) {
   if (threadIdx.x == 0) { st->prefix = 0ull; st->rank = rank; }
 }
 
+// One radix pass: histogram of byte (shift) over the entries whose higher bytes equal the prefix found so far.
+// A workgroup walks whole rows (no per-element division), 16 bytes per lane when n % 4 == 0.  Similarities are
+// concentrated — in the first passes nearly every entry lands in one or two bins — so a lane counts runs of equal
+// bins in a register and touches the LDS histogram only when the bin changes.
 __global__ __launch_bounds__(256) void median_hist_kernel(const float* __restrict__ K, int64_t n, MedianState* st,
                                                           int shift) {
   __shared__ unsigned int lh[256];
@@ -39,13 +43,32 @@ __global__ __launch_bounds__(256) void median_hist_kernel(const float* __restric
   __syncthreads();
   const uint32_t prefix = (uint32_t)st->prefix;
   const uint32_t himask = (shift == 24) ? 0u : (0xffffffffu << (shift + 8));
-  const int64_t total = n * n;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = e / n, j = e - i * n;
-    if (i == j) continue;
-    const uint32_t o = f2ord(K[e]);
-    if ((o & himask) == (prefix & himask)) atomicAdd(&lh[(o >> shift) & 255u], 1u);
+  const uint32_t want = prefix & himask;
+  uint32_t cur = 0xffffffffu, run = 0;
+  auto feed = [&](float v) {
+    const uint32_t o = f2ord(v);
+    if ((o & himask) != want) return;
+    const uint32_t bin = (o >> shift) & 255u;
+    if (bin == cur) { ++run; return; }
+    if (run) atomicAdd(&lh[cur], run);
+    cur = bin; run = 1;
+  };
+  const bool vec = ((n & 3) == 0) && ((reinterpret_cast<uintptr_t>(K) & 15) == 0);
+  for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const float* row = K + i * n;
+    if (vec) {
+      for (int64_t j = (int64_t)threadIdx.x * 4; j < n; j += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (j + e != i) feed(v[e]);
+      }
+    } else {
+      for (int64_t j = threadIdx.x; j < n; j += 256)
+        if (j != i) feed(row[j]);
+    }
   }
+  if (run) atomicAdd(&lh[cur], run);
   __syncthreads();
   if (lh[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
 }
@@ -72,9 +95,7 @@ int launch_offdiag_lower_median(const float* K, int64_t n, float* out, uint32_t*
   const unsigned long long cnt = (unsigned long long)n * (unsigned long long)(n - 1);
   hipLaunchKernelGGL(median_init_kernel, dim3(1), dim3(256), 0, s, st, (cnt - 1) / 2);
   MMF_LAUNCH_CHECK();
-  const int64_t total = n * n;
-  int64_t grid = (total + 256 * 8 - 1) / (256 * 8);
-  if (grid > 2048) grid = 2048;
+  int64_t grid = n < 4096 ? n : 4096;          // workgroups take whole rows
   if (grid < 1) grid = 1;
   for (int shift = 24; shift >= 0; shift -= 8) {
     hipLaunchKernelGGL(median_hist_kernel, dim3((unsigned)grid), dim3(256), 0, s, K, n, st, shift);
