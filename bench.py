@@ -26,9 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {1: 157.3, 2: 2500.0, 3: 2500.0}   # f32 MFMA; f16 / bf16 MFMA dense (MI355X_MICROARCH.md)
-_SHAPE = "32x32x16" if os.environ.get("MMF_SCAN_SHAPE") == "32" else "16x16x32"
-SCAN_NAME = {1: "scan_f32 (v_mfma_f32_32x32x2_f32)", 2: f"scan_b16x<f16> (v_mfma_f32_{_SHAPE}_f16)",
-             3: f"scan_b16x<bf16> (v_mfma_f32_{_SHAPE}_bf16)"}
+SCAN_NAME = {1: "scan_f32 (v_mfma_f32_32x32x2_f32)", 2: "scan_b16x<f16> (v_mfma_f32_16x16x32_f16)",
+             3: "scan_b16x<bf16> (v_mfma_f32_16x16x32_bf16)"}
 
 
 def make_rows(lo: int, hi: int, d: int, device, block: int = 4096):

@@ -505,12 +505,6 @@ struct SlotList {
   }
 };
 
-// C layout of v_mfma_f32_32x32x*: lane (column, half = lane >> 5), element r -> row
-struct RowOf32 {
-  int half;
-  __device__ __forceinline__ uint32_t operator()(int r) const { return (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * half); }
-};
-
 __device__ __forceinline__ float max16(const f32x16& v) {
   float a = fmaxf(fmaxf(v[0], v[1]), v[2]);
   float b = fmaxf(fmaxf(v[3], v[4]), v[5]);

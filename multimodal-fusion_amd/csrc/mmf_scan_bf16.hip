@@ -198,313 +198,10 @@ __device__ __forceinline__ void glds4(const void* gptr, const void* lptr) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 4, 0, 0);
 }
 
-// NW waves per workgroup (32 queries each), TPB tiles per barrier (2 * TPB tile stages in LDS):
-//   d <= 512 : NW = 8 (two waves per SIMD, 256 VGPRs each), TPB = 2
-//   d <= 1024: NW = 4 (one wave per SIMD, the 256 VGPRs of resident query fragments spill over into AGPRs), TPB = 1
-template <int KS, bool F16, bool DBG, int NW, int TPB, int CAP>
-__global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16_kernel(ScanB16Args a) {
-  constexpr int NT = 64 * NW;
-  constexpr int QT = 32 * NW;
-  constexpr int STAGES = 2 * TPB;
-  constexpr int ROWB = KS * 32;                 // bytes per candidate row in LDS (= DP * 2)
-  constexpr int TILEB = B_CT * ROWB;            // bytes per tile
-  constexpr int PIECES = TILEB / 1024;          // 1 KiB DMA pieces per tile (= KS)
-  constexpr int PPW = (PIECES + NW - 1) / NW;
-  static_assert(PIECES % NW == 0, "piece distribution");
-  extern __shared__ __attribute__((aligned(1024))) char smem[];
-  char* tiles = smem;                                                  // [STAGES][TILEB]
-  float* cbs = reinterpret_cast<float*>(smem + STAGES * TILEB);      // [STAGES][64]
-  // Candidate lists (SlotList, mmf_dev.h): approximate keys in LDS, column ids in a global slot block of
-  // this workgroup — leaving most of LDS to the tile ring is what buys the fourth stage.
-  float* lkeys = cbs + STAGES * 64;                                  // [CAP][NT]
-  uint32_t* lids = a.lids + (size_t)blockIdx.x * (16 * NT);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5;
-  const int c = lane & 31;
-
-  // XCD-aware block -> (row block, split): blocks that share blockIdx % 8 share an XCD (observed
-  // round-robin placement; speed only) and are given the same column range, so its tiles are L2 hits.
-  // Splits beyond the `conc_splits` that run side by side follow in later rounds of block ids, i.e. later in
-  // dispatch order: their workgroups start from the thresholds the earlier ones published (a.seed).
-  int64_t rb;
-  int split;
-  {
-    const int CS = a.conc_splits;
-    const int64_t round = blockIdx.x / a.blocks_per_round;
-    const int64_t j = blockIdx.x - round * a.blocks_per_round;
-    const int64_t q = j >> 3;
-    const int x = (int)(j & 7);
-    split = (int)round * CS + x % CS;
-    rb = q * (8 / CS) + x / CS;
-  }
-  if (rb >= a.row_blocks) return;
-  const int64_t q0 = rb * QT;
-  int64_t t_begin = (int64_t)split * a.tiles_per_split;
-  int64_t t_end = t_begin + a.tiles_per_split;
-  if (t_end > a.tiles_total) t_end = a.tiles_total;
-  if (t_begin > t_end) t_begin = t_end;
-  const int64_t T = t_end - t_begin;
-
-  const int64_t qpos = q0 + 32 * wave + c;
-  const bool qvalid = qpos < a.n_rows;
-
-  // margin of this lane's query (see the header): 2 (E1 + E2)
-  float margin;
-  {
-    const float ZB = __uint_as_float(a.maxima[0]), RB = __uint_as_float(a.maxima[1]);
-    const float UB = __uint_as_float(a.maxima[2]), CB = __uint_as_float(a.maxima[3]);
-    const float zn = a.q_zn[qpos], rn = a.q_rn[qpos], un = a.q_un[qpos];   // arrays are padded
-    const float g_acc = (float)(KS * 16 + 8) * 5.9604645e-8f;
-    const float g_chain = (float)(a.d + 2) * 5.9604645e-8f;
-    // + 2^-19 |G|: the 4 slot bits a stored key carries in its low mantissa bits (SlotList)
-    const float e1 = rn * ZB + un * RB + (g_acc + 1.9073486e-6f) * (zn * ZB + CB);
-    float e2;
-    if (a.metric == MMF_DOT) e2 = g_chain * un * UB;
-    else if (a.metric == MMF_COSINE) e2 = (g_chain + 4.7683716e-7f) * un * UB * 1.01f;
-    else e2 = g_chain * un * UB + 2.3841858e-7f * (un * un + UB * UB);
-    margin = 2.0f * (e1 + e2) * 1.001f + 1e-30f;
-  }
-
-  SlotList<CAP, NT> list;
-  list.init(lkeys + tid, lids + tid);
-  if (!qvalid) list.thr = __builtin_huge_valf();
-  // Thresholds are shared between the workgroups (and launches) that scan different columns for the same
-  // queries: any list's threshold bounds the approximate key of every member of the final top-k, whatever
-  // columns it sits in.  sync_seed publishes this lane's threshold when it has risen (and is not the product
-  // of a dropped key) and adopts the best one published so far; it runs at the start and every 64 tiles.
-  float pub = -kFltMax;
-  auto sync_seed = [&]() {
-    if (!qvalid) return;
-    if (list.thr > pub && list.thr > list.lost) {
-      pub = list.thr;
-      atomicMax(a.seed + qpos, seed_enc(pub));
-    }
-    if (!a.share) return;
-    const int32_t o = __hip_atomic_load(a.seed + qpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (o > kSeedNone) {
-      const float t = __int_as_float(o >= 0 ? o : (o ^ 0x7fffffff));
-      if (t > list.thr) { list.thr = t; pub = t; }
-    }
-  };
-  if (a.share) sync_seed();
-  // a wave whose queries all start from a published threshold skips the cold-start treatment
-  const bool seeded = !__any(list.thr == -kFltMax);
-
-  // resident query fragments: B operand, lane (c, half) holds Z[q0 + 32w + c][16 s + 8 half .. +7]
-  u32x4 qf[KS];
-  {
-    const char* qb = reinterpret_cast<const char*>(a.ZQ) + (q0 + 32 * wave + c) * (int64_t)ROWB + half * 16;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const u32x4*>(qb + s * 32);
-    // make the compiler retire these loads HERE: otherwise it cannot prove them complete at their
-    // first use inside the tile loop and puts s_waitcnt vmcnt(0) there, which drains the tile DMA
-    // in flight on every iteration
-#pragma unroll
-    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[s]));
-  }
-
-  // A-fragment read offsets inside a tile: row c, chunk (2s + half) ^ (c & 15)
-  int lo[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) lo[j] = c * ROWB + ((((2 * j + half) ^ (c & 15)) & 15) << 4);
-
-  // DMA roles: piece p of a tile covers LDS bytes [1024 p, 1024 p + 1024); lane writes 16 B at l*16.
-  // Source = wave-uniform running tile pointer + a loop-invariant 32-bit lane offset.
-  uint32_t src_off[PPW];
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) {
-    const int p = wave + NW * i;
-    const int off = p * 1024 + lane * 16;
-    const int r = off / ROWB;
-    const int chunk = (off % ROWB) >> 4;
-    const int src_chunk = (chunk & ~15) | ((chunk ^ r) & 15);
-    src_off[i] = (uint32_t)(r * ROWB + src_chunk * 16);
-  }
-  const char* zc0 = reinterpret_cast<const char*>(a.ZC) + t_begin * (int64_t)TILEB;          // tile 0 of my range
-  const char* cb0 = reinterpret_cast<const char*>(a.cb + t_begin * B_CT);
-  // Tile pieces go through the buffer form of the LDS-DMA: the workgroup's column range is one raw buffer
-  // (base = its first tile), the running tile position is the scalar offset and the lane's swizzled position
-  // the vector offset — no per-piece 64-bit address arithmetic in the MFMA chain, and (unlike the FLAT-encoded
-  // global form) it leaves the compiler's counted lgkmcnt waits for the A-fragment ring intact.
-  const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(zc0), 0, -1, 0x00020000);
-  auto issue_piece = [&](const char* tsrc, int stage, int i) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(zrsrc, (__attribute__((address_space(3))) void*)(tiles + stage * TILEB + (wave + NW * i) * 1024),
-                                             16, (int)src_off[i], (int)(uint32_t)(tsrc - zc0), 0, 0);
-  };
-  // the 32 biases of a tile: one 4-byte DMA by lanes 0..31 of the wave whose turn it is
-  auto issue_bias = [&](const char* bsrc, int stage) {
-    const uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // lane id, no live VGPR
-    if (l < 32) glds4(bsrc + l * 4u, cbs + stage * 64);
-  };
-
-  const int Ti = (int)T;
-  if (Ti > 0) {   // first group of TPB tiles -> stages 0 .. TPB-1
-#pragma unroll
-    for (int u = 0; u < TPB; ++u) {
-      const bool real = u < Ti;
-#pragma unroll
-      for (int i = 0; i < PPW; ++i) issue_piece(real ? zc0 + u * (int64_t)TILEB : zc0, u, i);
-      if (wave == (u & (NW - 1))) issue_bias(real ? cb0 + u * B_CT * 4 : cb0, u);
-    }
-  }
-  // The DMA pieces of tile t+TPB are issued inside the MFMA chain of tile t, one per group of GRP MFMAs.  The
-  // chain is straight-line code and the DMA is unconditional — past the end of the range it re-fetches tile 0
-  // into a stage nobody reads again — so no branch and no per-tile bookkeeping sits between the MFMAs.
-  // (Issuing at different points of the chain for the two waves that share a SIMD used to pay when a piece cost
-  // 64-bit address arithmetic; with the buffer form it measures 0.8 % slower than issuing at the same point.)
-  constexpr int GRP = KS / PPW;                      // MFMAs between two DMA pieces
-  const char* tsrc = zc0 + TPB * (int64_t)TILEB;     // source of the first tile of the NEXT group
-  const char* bsrc = cb0 + TPB * B_CT * 4;
-  const uint32_t id_base = (uint32_t)(t_begin * B_CT);
-
-  auto tile_body = [&](const char* tb, const float* cbt, const char* src, int s2) -> f32x16 {
-    f32x16 acc;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(cbt + 8 * g + 4 * half);
-      acc[4 * g + 0] = b4[0]; acc[4 * g + 1] = b4[1]; acc[4 * g + 2] = b4[2]; acc[4 * g + 3] = b4[3];
-    }
-    // A fragments are read PD k-steps ahead of the MFMA that consumes them (explicit register
-    // ring): the chain never waits on an LDS read it has just issued.
-    constexpr int PD = 4;
-    u32x4 af[PD];
-#pragma unroll
-    for (int s = 0; s < PD; ++s) af[s] = *reinterpret_cast<const u32x4*>(tb + lo[s & 7] + (s >> 3) * 256);
-    __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);   // the PD leading reads first
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const u32x4 cur = af[s % PD];
-      if (s + PD < KS) af[s % PD] = *reinterpret_cast<const u32x4*>(tb + lo[(s + PD) & 7] + ((s + PD) >> 3) * 256);
-      if constexpr (F16)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, cur), __builtin_bit_cast(f16x8_t, qf[s]), acc, 0, 0, 0);
-      else
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, cur), __builtin_bit_cast(bf16x8_t, qf[s]), acc, 0, 0, 0);
-      // one DMA piece of tile t+TPB per group of GRP MFMAs
-      if ((s % GRP) == GRP - 1) issue_piece(src, s2, s / GRP);
-      // pin the interleave: one LDS read (for step s+PD), then one MFMA (step s); hipcc otherwise
-      // falls back to read -> lgkmcnt(0) -> use pairs to save registers
-      if (s + PD < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    }
-    return acc;
-  };
-
-  // The filter of tile t-1 runs AFTER barrier t, ahead of this wave's own MFMA chain: a wave that
-  // falls into the (rare) list code then delays only itself while its SIMD partner issues MFMAs;
-  // placed before the barrier it would hold all eight waves, and their matrix pipes, at the barrier.
-  auto filter = [&](const f32x16& acc, int tt, float mx) {
-    if (!(DBG && (a.debug & 1)) && __any(mx >= list.thr)) {
-      const uint32_t id0 = id_base + (uint32_t)tt * B_CT;
-      // robust (never dropping) path while thresholds are still forming: first 32 tiles of the range
-      const bool cold = (!seeded && tt < 32) || __any(list.thr == -kFltMax);
-      if (DBG && (a.debug & 8)) {
-        const bool willc = __any(list.cnt >= CAP - 1);
-        int nh = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) nh += (acc[r] >= list.thr) ? 1 : 0;
-        const int lanes_hit = __popcll(__ballot(nh > 0));
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) nh += __shfl_xor(nh, o);
-        if (lane == 0) {
-          atomicAdd(a.dbg + 0, 1ull);                       // slow-path entries
-          atomicAdd(a.dbg + 1, cold ? 1ull : 0ull);         // ... of which cold
-          atomicAdd(a.dbg + 2, (unsigned long long)nh);     // hits (values >= thr)
-          atomicAdd(a.dbg + 3, (!cold && willc) ? 1ull : 0ull);   // warm compactions
-          atomicAdd(a.dbg + 4, (unsigned long long)lanes_hit);
-        }
-      }
-      unsigned long long ts0 = 0;
-      if (DBG && (a.debug & 16)) ts0 = __builtin_amdgcn_s_memtime();
-      list.offer_tile(acc, id0, RowOf32{half}, a.kk, margin);
-      if (DBG && (a.debug & 16) && lane == 0) {
-        const unsigned long long dt = __builtin_amdgcn_s_memtime() - ts0;
-        atomicAdd(a.dbg + (cold ? 4 : 5), dt);
-        atomicAdd(a.dbg + (cold ? 6 : 7), 1ull);
-      }
-    }
-    if (DBG && (a.debug & 8) && lane == 0) atomicAdd(a.dbg + 5, 1ull);   // tiles
-    if (a.share && (tt & 63) == 63) sync_seed();
-  };
-
-  // Main loop: TPB tiles per barrier.  Iteration j reads the group of stages holding tiles j*TPB ..
-  // and fills the other group with the next TPB tiles (DMA pieces issued inside the MFMA chains), so at
-  // the top of an iteration everything this wave has in flight is exactly what the iteration needs:
-  // vmcnt(0), barrier.  Past the end of the range the DMA re-fetches tile 0 into a stage nobody reads.
-  unsigned long long tw = 0, tf = 0, tc = 0, t0s = 0, t1s = 0, t2s = 0, t3s = 0;
-  const bool stamps = DBG && (a.debug & 16) != 0;
-  f32x16 acc_prev;
-  float mx_prev = kNegInf;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc_prev[r] = kNegInf;      // "tile -1": nothing can hit
-  const int nIter = (Ti + TPB - 1) / TPB;
-  for (int j = 0; j < nIter; ++j) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) alone (expcnt 7, lgkmcnt 15 = no wait)
-    if (stamps) t0s = __builtin_amdgcn_s_memtime();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // this group is visible to all; everyone is done READING the other group
-    asm volatile("" ::: "memory");
-    if (stamps) t1s = __builtin_amdgcn_s_memtime();
-
-    filter(acc_prev, j * TPB - 1, mx_prev);  // behind the barrier: only this wave waits for its own list code
-    if (stamps) t2s = __builtin_amdgcn_s_memtime();
-
-    const int sg = (j & 1) * TPB, ng = TPB - sg;      // stage group read / filled by this iteration
-#pragma unroll
-    for (int u = 0; u < TPB; ++u) {
-      const int t = j * TPB + u;
-      const bool more = (t + TPB < Ti);
-      const char* src = more ? tsrc + u * (int64_t)TILEB : zc0;
-      f32x16 acc;
-      acc = tile_body(tiles + (sg + u) * TILEB, cbs + (sg + u) * 64, src, ng + u);
-      if (wave == ((t + TPB) & (NW - 1))) issue_bias(more ? bsrc + u * B_CT * 4 : cb0, ng + u);
-      if (u < TPB - 1) {
-        filter(acc, t, max16(acc));   // mid-iteration, no barrier nearby
-      } else {
-        if (t >= Ti) {              // ragged range: the last tile of the last group is a dummy
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = kNegInf;
-        }
-        acc_prev = acc;
-        mx_prev = max16(acc);         // reduced BEFORE the barrier, in time this wave would otherwise spend waiting
-      }
-    }
-    tsrc += TPB * (int64_t)TILEB;
-    bsrc += TPB * B_CT * 4;
-    if (stamps) {
-      asm volatile("" :: "v"(acc_prev[0]));          // the chain's result must exist before the stamp
-      t3s = __builtin_amdgcn_s_memtime();
-      tw += t1s - t0s; tf += t2s - t1s; tc += t3s - t2s;
-    }
-  }
-  if (stamps && lane == 0) {
-    atomicAdd(a.dbg + 0, tw); atomicAdd(a.dbg + 1, tf); atomicAdd(a.dbg + 2, tc); atomicAdd(a.dbg + 3, (unsigned long long)Ti);
-  }
-  if (Ti > 0) filter(acc_prev, nIter * TPB - 1, max16(acc_prev));
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // the dummy tiles still in flight
-
-  list.compact(a.kk, margin);
-  sync_seed();
-  if (qvalid) {
-    const int64_t lbase = qpos * a.lists_total + a.list_base + 2 * split + half;
-    a.cand_cnt[lbase] = (uint32_t)list.cnt;
-    for (int e = 0; e < list.cnt; ++e) {
-      uint32_t id = list.id_of(e);
-      if (a.seg_len) id = (id / a.seg_len) * a.seg_stride + id % a.seg_len;
-      a.cand_ids[lbase * CAP + e] = id + a.id_off;
-      if (a.cand_keys) a.cand_keys[lbase * CAP + e] = list.keys[e * NT];
-    }
-    // Audited loss, settled after the last launch: a dropped candidate matters only if its key reaches the
-    // best threshold ANY list of the row has proven by then.
-    if (a.cand_keys && half == 0) a.margin_out[qpos] = margin;
-    if (list.lost > kNegInf) atomicMax(a.lost + qpos, seed_enc(list.lost) + 16);   // +16 ulp: stored keys carry slot bits
-  }
-}
-
-// The same scan on v_mfma_f32_16x16x32_{f16,bf16}: identical operand bytes, LDS image and cycles per flop, but the
-// chip holds a higher clock on this shape under load (MI355X_MICROARCH.md "DVFS give-back" item 7).
+// MFMA shape: v_mfma_f32_16x16x32_{f16,bf16}.  The kernel was first written on the 32x32x16 shape (one 32 x 32 tile
+// per wave, a lane = one query x 16 candidates); operand bytes, LDS image and cycles per flop are identical, but the
+// chip holds a higher clock on 16x16x32 under load (MI355X_MICROARCH.md "DVFS give-back" item 7): 10 % less wall
+// time on the same box (profiles/README.md; the 32x32x16 form is in the history, commit "scan on v_mfma_f32_16x16x32").
 // C layout per 16x16 tile: lane l -> column l & 15, rows 4 (l >> 4) + {0..3}.  A wave covers its 32 queries x the
 // 32 candidates of a tile with 2 x 2 tiles acc[cb][qb]: a lane holds TWO queries (l & 15, + 16) x 8 candidates.
 // The list code keeps its "one lane = one query, 16 candidates" form: lane l owns query (l & 15) + 16 ((l >> 4) & 1);
@@ -618,7 +315,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
       qf[s][0] = *reinterpret_cast<const u32x4*>(qbase + s * 64);
       qf[s][1] = *reinterpret_cast<const u32x4*>(qbase + 16 * (int64_t)ROWB + s * 64);
     }
-    // make the compiler retire these loads HERE (see scan_b16_kernel)
+    // make the compiler retire these loads HERE: otherwise it cannot prove them complete at their first use
+    // inside the tile loop and puts s_waitcnt vmcnt(0) there, which drains the tile DMA in flight every iteration
 #pragma unroll
     for (int s = 0; s < KS2; ++s) { asm volatile("" : "+v"(qf[s][0])); asm volatile("" : "+v"(qf[s][1])); }
   }
@@ -948,15 +646,6 @@ static int launch_b16_t(const ScanB16Args& a, bool f16, int64_t grid, hipStream_
     MMF_LAUNCH_CHECK();
     return MMF_OK;
   };
-  static const bool shape32 = [] { const char* e = getenv("MMF_SCAN_SHAPE"); return e && atoi(e) == 32; }();
-  if (shape32) {          // the v_mfma_f32_32x32x16 form of the kernel (A/B reference)
-    if (a.debug != 0) {
-      if (f16) return go(scan_b16_kernel<KS, true, true, NW, TPB, CAP>);
-      return go(scan_b16_kernel<KS, false, true, NW, TPB, CAP>);
-    }
-    if (f16) return go(scan_b16_kernel<KS, true, false, NW, TPB, CAP>);
-    return go(scan_b16_kernel<KS, false, false, NW, TPB, CAP>);
-  }
   if (a.debug != 0) {   // instrumented build of the same kernel (MMF_SCAN_DEBUG)
     if (f16) return go(scan_b16x_kernel<KS, true, true, NW, TPB, CAP>);
     return go(scan_b16x_kernel<KS, false, true, NW, TPB, CAP>);
