@@ -84,3 +84,39 @@ def test_flagged_rows_take_the_exact_paths(mmf, monkeypatch, flag_rows, metric, 
     r2 = mmf.simtopk(X[:2000], Y, metric=metric, lam=0.5, k=4, precision="exact", exclude_self=True, row_offset=1000, col_offset=900)
     o2 = mmf.simtopk(X[:2000], Y, metric=metric, lam=0.5, k=4, precision="fast", exclude_self=True, row_offset=1000, col_offset=900)
     assert torch.equal(o2[0], r2[0]) and torch.equal(o2[1], r2[1])
+
+
+def test_random_configurations_against_the_oracle(mmf):
+    """Seeded sweep over shapes the parametrised tests do not enumerate: ragged n / m / d, every metric and dtype,
+    offsets, self-exclusion on rectangular overlaps, k up to the list limits, forced column splits."""
+    import oracle
+    rng = np.random.RandomState(20261004)
+    metrics = ["cosine", "dot", "neg_sq_l2", "rbf"]
+    dtypes = [torch.float32, torch.float16, torch.bfloat16]
+    for case in range(36):
+        n = int(rng.randint(1, 700))
+        m = int(rng.randint(40, 3000))
+        d = int(rng.choice([1, 2, 3, 7, 16, 31, 64, 100, 129, 255, 256, 300, 512, 513, 777, 1024, 1100]))
+        k = int(rng.randint(1, 13))
+        metric = metrics[case % 4]
+        dt = dtypes[(case // 4) % 3]
+        excl = bool(rng.randint(0, 2))
+        ro, co = int(rng.randint(0, 50)), int(rng.randint(0, 50))
+        splits = int(rng.choice([0, 0, 1, 2, 8]))
+        k = min(k, m - 1)
+        scale = 0.05 if metric == "rbf" else 1.0
+        g = torch.Generator(device="cuda").manual_seed(1000 + case)
+        X = (torch.randn((n, d), generator=g, device="cuda") * scale).to(dt)
+        Y = (torch.randn((m, d), generator=g, device="cuda") * scale).to(dt)
+        if case % 5 == 0:
+            Y[: min(n, m)] = X[: min(n, m)]                                     # duplicates: exact ties, self columns
+        idx, val = mmf.simtopk(X, Y, metric=metric, lam=0.7, k=k, exclude_self=excl, row_offset=ro, col_offset=co,
+                               col_splits=splits)
+        ri, rv = oracle.simtopk(X.float().cpu().numpy(), Y.float().cpu().numpy(), metric=metric, lam=0.7, k=k,
+                                exclude_self=excl, row_offset=ro, col_offset=co)
+        tag = (case, n, m, d, k, metric, dt, excl, ro, co, splits)
+        assert np.array_equal(idx.cpu().numpy(), ri), tag
+        if metric == "rbf":
+            assert np.allclose(val.cpu().numpy(), rv, rtol=0, atol=1e-5), tag
+        else:
+            assert np.array_equal(val.cpu().numpy(), rv), tag
