@@ -141,11 +141,15 @@ __global__ __launch_bounds__(256) void prep_half_kernel(PrepArgs a) {
     if (lane == 0) { a.zn[row] = zn; a.rn[row] = rn; a.un[row] = un; a.cb[row] = cb; }
     m_zn = fmaxf(m_zn, zn); m_rn = fmaxf(m_rn, rn); m_un = fmaxf(m_un, un); m_cb = fmaxf(m_cb, fabsf(cb));
   }
-  if (lane == 0) {   // non-negative floats order like their bits
-    if (m_zn > 0.f) atomicMax(a.maxima + 0, __float_as_uint(m_zn));
-    if (m_rn > 0.f) atomicMax(a.maxima + 1, __float_as_uint(m_rn));
-    if (m_un > 0.f) atomicMax(a.maxima + 2, __float_as_uint(m_un));
-    if (m_cb > 0.f) atomicMax(a.maxima + 3, __float_as_uint(m_cb));
+  // Publish once per WORKGROUP: same-address atomics retire at about 90 per microsecond, so one set per wave
+  // (16384 x 4 of them) used to be most of this kernel's time.  Non-negative floats order like their bits.
+  __shared__ float wmax[4][4];
+  const int w = threadIdx.x >> 6;
+  if (lane == 0) { wmax[w][0] = m_zn; wmax[w][1] = m_rn; wmax[w][2] = m_un; wmax[w][3] = m_cb; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const float m = fmaxf(fmaxf(wmax[0][threadIdx.x], wmax[1][threadIdx.x]), fmaxf(wmax[2][threadIdx.x], wmax[3][threadIdx.x]));
+    if (m > 0.f) atomicMax(a.maxima + threadIdx.x, __float_as_uint(m));
   }
 }
 
@@ -603,7 +607,7 @@ int launch_prep_half(const void* X, int64_t n, int64_t d, int dtype, int metric,
                      float* un, float* cb, uint32_t* maxima, hipStream_t s) {
   PrepArgs a{X, n, d, dtype, metric, scal, max_n, Z, n_pad, dp, z_f16, zn, rn, un, cb, maxima};
   int64_t grid = (n_pad + 3) / 4;
-  if (grid > 4096) grid = 4096;
+  if (grid > 1024) grid = 1024;          // 16 waves per CU; fewer, longer workgroups keep the final atomics few
   hipLaunchKernelGGL(prep_half_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
   MMF_LAUNCH_CHECK();
   return MMF_OK;
