@@ -147,8 +147,12 @@ struct FastTail {
   int32_t* seed = nullptr;
   // a handful of flagged rows skips the matrix-core rescan: all their keys, then a block-wide top-k
   static constexpr int64_t kRowsExactMax = 48;
+  // overflow slots per row for the columns a row's lane lists cannot hold (near-duplicate data); a row that fills
+  // them as well is redone exactly
+  static constexpr int kSpillCap = 192;
   int64_t rows_exact_cap = 0;
   float* row_keys = nullptr;
+  int32_t* defer_rows = nullptr; uint32_t* defer_count = nullptr;
   // m_panel_min: columns of the smallest panel (== m_ when the scan is one launch); `splits` is per launch
   FastTail(int64_t n_, int64_t m_, int kk_, int cap_, int forced_splits, int dp_, int panels_ = 1, int64_t m_panel_min = -1)
       : n(n_), m(m_), kk(kk_), cap(cap_), dp(dp_), panels(panels_) {
@@ -160,7 +164,7 @@ struct FastTail {
     splits = 1;
     if (forced_splits > 0) { while (splits < forced_splits) splits <<= 1; }
     else { while (row_blocks * splits < 256 && splits < 32) splits <<= 1; }
-    while (splits > 1 && (splits > col_tiles || 2 * splits * panels * bcap > 1024)) splits >>= 1;
+    while (splits > 1 && (splits > col_tiles || 2 * splits * panels * bcap > 1024 - kSpillCap)) splits >>= 1;
     // The first half of the panels runs while the rest of the exchange is still on the wire and its kernel
     // holds compute units.  MMF_PANEL_FRONT_FACTOR = 2 or 4 gives those launches that many times the workgroups
     // (shorter ones), which shortens the tail the late-joining units leave — measured with a stand-in kernel
@@ -174,7 +178,7 @@ struct FastTail {
       panel_splits[p] = sp;
       total_splits += sp;
     }
-    if (2 * total_splits * bcap > 1024) {            // too many lists for the select kernel: uniform
+    if (2 * total_splits * bcap > 1024 - kSpillCap) { // too many lists for the select kernel: uniform
       total_splits = splits * panels;
       for (int p = 0; p < panels && p < 16; ++p) panel_splits[p] = splits;
     }
@@ -192,7 +196,7 @@ struct FastTail {
     return ws_bytes((size_t)n * lists, 4) + 2 * ws_bytes((size_t)n * lists * bcap, 4) + 3 * ws_bytes(n, 4) + ws_bytes(4, 4) +
            ws_bytes(256, 4) + ws_bytes((size_t)FB * fb_lists, 4) + ws_bytes((size_t)FB * fb_lists * cap, 4) +
            2 * ws_bytes(FB, 4) + ws_bytes(4, 4) + ws_bytes(scan_b16_scratch_bytes(n, max_splits, dp), 1) + ws_bytes(2 * n_seed, 4) +
-           ws_bytes((size_t)rows_exact_cap * m, 4);
+           ws_bytes((size_t)rows_exact_cap * m, 4) + ws_bytes(n, 4) + ws_bytes((size_t)n * kSpillCap, 4) + ws_bytes(n, 4) + ws_bytes(4, 4);
   }
   void carve(Workspace& ws) {
     L.cnt = ws.take<uint32_t>((size_t)n * lists);
@@ -214,6 +218,11 @@ struct FastTail {
     seed = ws.take<int32_t>(2 * n_seed);
     if (lists <= 2) { L.keys = nullptr; L.margin = nullptr; }    // one list pair per row: nothing to prune against
     row_keys = ws.take<float>((size_t)rows_exact_cap * m);
+    L.spill_cnt = ws.take<uint32_t>(n);
+    L.spill_ids = ws.take<uint32_t>((size_t)n * kSpillCap);
+    L.spill_cap = kSpillCap;
+    defer_rows = ws.take<int32_t>(n);
+    defer_count = ws.take<uint32_t>(4);
   }
   int run(const void* X, int64_t n_, const void* Y, int64_t m_, int64_t d, int in_dtype, int metric, float lambda, int k,
           int exclude_self, int64_t row_offset, int64_t col_offset, const FastOperands& fo, int64_t* out_idx,
@@ -224,6 +233,8 @@ struct FastTail {
     EventTimer t_scan, t_sel, t_fb;
     int grid = 0;
     MMF_HIP(hipMemsetAsync(seed, 0x80, (size_t)n_seed * 8, s));   // kSeedNone, thresholds and dropped keys
+    MMF_HIP(hipMemsetAsync(L.spill_cnt, 0, (size_t)n * 4, s));
+    MMF_HIP(hipMemsetAsync(defer_count, 0, 16, s));
     MMF_TRY(t_scan.start(profile, s));
     ScanB16Panel pn;
     pn.seed = seed; pn.seed_stride = n_seed;
@@ -260,6 +271,7 @@ struct FastTail {
     q.k = k; q.exclude_self = exclude_self; q.row_offset = row_offset; q.col_offset = col_offset;
     q.rx = fo.rx; q.cy = fo.cy; q.row_ids = nullptr; q.n_rows = n; q.out_idx = out_idx; q.out_val = out_val;
     q.fail_rows = fail_rows; q.fail_count = fail_count; q.cand_total = stats ? cand_total : nullptr;
+    q.defer_rows = defer_rows; q.defer_count = defer_count;
     MMF_TRY(t_sel.start(profile, s));
     MMF_TRY(launch_select(q, L, s));
     MMF_TRY(t_sel.stop(s));

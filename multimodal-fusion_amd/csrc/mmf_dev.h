@@ -379,9 +379,30 @@ struct LaneList {
 // slot bits perturb a key by are part of the error margin (scan kernel, E1).
 // Thresholds, partner-lane merge and the audited-loss rule are those of LaneList.
 // ---------------------------------------------------------------------------------------------
+// Where a full list puts what it cannot hold: the row's overflow list in global memory (one counter + `cap` id
+// slots per query, shared by every lane, workgroup and launch that scans the query).  Near-duplicate data puts far
+// more columns inside a query's margin band than a list has entries; they are kept here, not dropped, and the
+// exact re-rank reads them with the lists.  cap == 0: no sink (a full list then loses the key, audited).
+struct SpillSink {
+  uint32_t* cnt = nullptr;    // [rows]
+  uint32_t* ids = nullptr;    // [rows][cap]
+  uint32_t cap = 0;
+  uint32_t seg_len = 0, seg_stride = 0, id_off = 0;   // operand column -> reported id (ScanB16Args)
+  int64_t row = 0;
+  __device__ __forceinline__ bool put(uint32_t id) const {
+    if (cap == 0) return false;
+    const uint32_t pos = atomicAdd(cnt + row, 1u);
+    if (pos >= cap) return false;
+    if (seg_len) id = (id / seg_len) * seg_stride + id % seg_len;
+    ids[row * cap + pos] = id + id_off;
+    return true;
+  }
+};
+
 template <int CAP, int NT>
 struct SlotList {
   static_assert(CAP <= 16, "4 slot bits");
+  SpillSink sink;
   float* keys;        // LDS, offset by threadIdx.x
   uint32_t* idslot;   // global, offset by threadIdx.x
   int cnt;
@@ -411,7 +432,8 @@ struct SlotList {
     if (nthr > thr) thr = nthr;
   }
 
-  // wave-wide; leaves at least two free slots (what it drops for that is recorded in `lost`)
+  // wave-wide; leaves at least two free slots (what it has to give up for that goes to the sink, or — without
+  // one, or with the sink full — is recorded in `lost`)
   __device__ __forceinline__ void compact(int kk, float margin) {
     float k[16];
 #pragma unroll
@@ -454,18 +476,15 @@ struct SlotList {
 #pragma unroll
     for (int e = 0; e < CAP; ++e) keep += ((e < cnt) && (k[e] >= thr)) ? 1 : 0;
     float cut = thr;
-    if (keep >= CAP - 1) {       // crowded: lossy truncation to the CAP-2 best
-      lost = fmaxf(lost, k[CAP - 2]);
-      thr = fmaxf(thr, lost);
-      cut = k[CAP - 3];
-    }
+    if (keep >= CAP - 1) cut = k[CAP - 3];   // crowded: only the CAP-2 best stay in the list
     int w = 0;
     uint32_t nused = 0;
     for (int e = 0; e < cnt; ++e) {     // in-place filter of the LDS keys, lane-private
       const float ke = keys[e * NT];
-      if (ke >= cut) {
-        if (w < CAP - 2) { keys[w * NT] = ke; nused |= 1u << (__float_as_uint(ke) & 15u); ++w; }
-        else lost = fmaxf(lost, ke);
+      if (ke >= cut && w < CAP - 2) {
+        keys[w * NT] = ke; nused |= 1u << (__float_as_uint(ke) & 15u); ++w;
+      } else if (ke >= thr) {           // still inside the band: to the overflow list, else lost (audited)
+        if (!sink.put(idslot[(__float_as_uint(ke) & 15u) * NT])) lost = fmaxf(lost, ke);
       }
     }
     thr = fmaxf(thr, lost);
@@ -496,7 +515,7 @@ struct SlotList {
       if (hit) {
         if (cnt < CAP) {
           push(x, id0 + rowof(r));
-        } else {
+        } else if (!sink.put(id0 + rowof(r))) {
           lost = fmaxf(lost, x);
           thr = fmaxf(thr, lost);
         }

@@ -92,6 +92,10 @@ struct CandLists {
   // lists per row, select drops what the union of the lists proves irrelevant before the exact re-rank
   float* keys = nullptr;
   float* margin = nullptr;   // [n]
+  // 16-bit scan only: per-row overflow lists (SpillSink, mmf_dev.h) — what the lane lists could not hold
+  uint32_t* spill_cnt = nullptr;   // [n], zeroed before the first launch
+  uint32_t* spill_ids = nullptr;   // [n][spill_cap], GLOBAL-mapped local column ids like `ids`
+  int spill_cap = 0;
 };
 
 // Where a launch of the 16-bit scan sits inside a paneled scan (all zero: the whole problem in one launch).
@@ -131,6 +135,7 @@ struct SelectProblem {
   int64_t* out_idx; float* out_val;
   int32_t* fail_rows; uint32_t* fail_count;   // rows whose lists overflowed (or came up short)
   uint32_t* cand_total;                        // optional accumulated candidate count
+  int32_t* defer_rows = nullptr; uint32_t* defer_count = nullptr;   // optional queue of the rows with overflow entries (count zeroed by the caller)
 };
 int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s);
 // exact top-k of a few rows (p.row_ids) against every column, no candidate lists; keys: p.n_rows * p.m floats

@@ -188,6 +188,7 @@ struct ScanB16Args {
   uint32_t* cand_cnt; uint32_t* cand_ids; uint32_t* overflow;
   float* cand_keys;          // approximate keys of the entries (select prunes with them), or nullptr
   float* margin_out;         // [n_rows] the queries' error margins, written with cand_keys
+  uint32_t* spill_cnt; uint32_t* spill_ids; int spill_cap;   // per-row overflow lists (SpillSink), or nullptr / 0
 };
 
 // Order-preserving float <-> int32 map (an involution) so that thresholds can be merged with atomicMax.
@@ -286,6 +287,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
   SlotList<CAP, NT> list;
   list.init(lkeys + tid, lids + tid);
   if (!qvalid) list.thr = __builtin_huge_valf();
+  else if (a.spill_cnt) {
+    list.sink.cnt = a.spill_cnt; list.sink.ids = a.spill_ids; list.sink.cap = (uint32_t)a.spill_cap; list.sink.row = qpos;
+    list.sink.seg_len = a.seg_len; list.sink.seg_stride = a.seg_stride; list.sink.id_off = a.id_off;
+  }
   // Thresholds are shared between the workgroups (and launches) that scan different columns for the same
   // queries: any list's threshold bounds the approximate key of every member of the final top-k, whatever
   // columns it sits in.  sync_seed publishes this lane's threshold when it has risen (and is not the product
@@ -701,6 +706,7 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
     }
   }
   a.cand_cnt = L.cnt; a.cand_ids = L.ids; a.overflow = L.overflow; a.cand_keys = L.keys; a.margin_out = L.margin;
+  a.spill_cnt = L.spill_cnt; a.spill_ids = L.spill_ids; a.spill_cap = L.spill_cap;
   const int64_t grid = scan_b16_grid(n_rows, col_splits, dp);
   a.lids = reinterpret_cast<uint32_t*>(scratch);
   if (grid_out) *grid_out = (int)grid;

@@ -23,6 +23,10 @@ struct SelectArgs {
   const int32_t* row_ids; int64_t n_rows;
   const uint32_t* cand_cnt; const uint32_t* cand_ids; const uint32_t* overflow; int lists; int cap;
   const float* cand_keys; const float* margin;      // optional: approximate keys of the entries + the row's error margin
+  const uint32_t* spill_cnt; const uint32_t* spill_ids; int spill_cap;   // optional: the row's overflow list
+  // staged kernel, two passes when overflow lists exist: pass 0 handles the rows without overflow entries in a lean
+  // LDS footprint and queues the others; pass 1 (room for the overflow entries) takes the queue
+  int pass; int32_t* defer_rows; uint32_t* defer_count;
   int64_t* out_idx; float* out_val;
   int32_t* fail_rows; uint32_t* fail_count; uint32_t* cand_total;
   int maxc;   // staged kernel: candidate slots per wave in dynamic LDS
@@ -84,8 +88,21 @@ __device__ __forceinline__ int gather_candidates(const SelectArgs& a, int64_t po
     }
     total += (int)cn;
   }
+  // the row's overflow list (columns the lane lists had no room for): appended after the pruning below, which
+  // works on approximate keys these entries do not carry
+  int n_sp = 0;
+  if (a.spill_cnt) {
+    const uint32_t c = a.spill_cnt[pos];
+    if (c > (uint32_t)a.spill_cap) return -1;            // the sink overflowed too: the scan recorded a lost key
+    n_sp = (int)c;
+  }
+  auto append_spill = [&](int at) -> int {
+    if (at + n_sp > maxc) return -1;
+    for (int e = lane; e < n_sp; e += 64) id[at + e] = a.spill_ids[pos * a.spill_cap + e];
+    return at + n_sp;
+  };
   const int kk = a.k + (a.exclude_self ? 1 : 0);
-  if (!prune || total <= kk) return total;
+  if (!prune || total <= kk) return append_spill(total);
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_wave_barrier();
   // t = kk-th largest approximate key: kk rounds of "best entry ranked after the previous pick" under
@@ -126,7 +143,7 @@ __device__ __forceinline__ int gather_candidates(const SelectArgs& a, int64_t po
     if (keep) id[kept + __popcll(mask & ((1ull << lane) - 1ull))] = ie;
     kept += __popcll(mask);
   }
-  return kept;
+  return append_spill(kept);
 }
 
 template <int METRIC, bool VEC4>
@@ -227,8 +244,17 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
   float (*xtile)[SC] = reinterpret_cast<float (*)[SC]>(sel_smem + sizeof(float) * SEL_WAVES * SG * SLD);
   float* skey_base = reinterpret_cast<float*>(sel_smem + sizeof(float) * SEL_WAVES * (SG * SLD + SC));
   uint32_t* sid_base = reinterpret_cast<uint32_t*>(skey_base + SEL_WAVES * maxc);
-  const int64_t pos = (int64_t)blockIdx.x * SEL_WAVES + wave;
-  if (pos >= a.n_rows) return;
+  int64_t pos = (int64_t)blockIdx.x * SEL_WAVES + wave;
+  if (a.pass == 1) {
+    if (pos >= (int64_t)*a.defer_count) return;
+    pos = a.defer_rows[pos];
+  } else {
+    if (pos >= a.n_rows) return;
+    if (a.defer_rows && a.overflow[pos] == 0 && a.spill_cnt[pos] != 0) {
+      if (lane == 0) a.defer_rows[atomicAdd(a.defer_count, 1u)] = (int32_t)pos;
+      return;
+    }
+  }
   const int64_t row = a.row_ids ? (int64_t)a.row_ids[pos] : pos;
   float* key = skey_base + wave * maxc;
   uint32_t* id = sid_base + wave * maxc;
@@ -357,12 +383,19 @@ template <int METRIC>
 static int launch_select_m(const SelectArgs& a, bool vec4, hipStream_t s) {
   const int64_t grid = (a.n_rows + SEL_WAVES - 1) / SEL_WAVES;
   if (vec4 && a.d >= 64) {
-    SelectArgs b = a;
-    b.maxc = ((a.lists * a.cap + 63) / 64) * 64;
-    const size_t lds = sizeof(float) * SEL_WAVES * (SG * SLD + SC) + (size_t)SEL_WAVES * b.maxc * 8;
     auto kern = select_staged_kernel<METRIC>;
-    MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * SEL_WAVES), lds, s, b);
+    const bool two = a.spill_cnt != nullptr && a.defer_rows != nullptr && a.row_ids == nullptr;
+    for (int pass = 0; pass < (two ? 2 : 1); ++pass) {
+      SelectArgs b = a;
+      b.pass = pass;
+      if (!two) b.defer_rows = nullptr;
+      const int extra = (two && pass == 0) ? 0 : a.spill_cap;
+      b.maxc = ((a.lists * a.cap + extra + 63) / 64) * 64;
+      const size_t lds = sizeof(float) * SEL_WAVES * (SG * SLD + SC) + (size_t)SEL_WAVES * b.maxc * 8;
+      MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * SEL_WAVES), lds, s, b);
+      MMF_LAUNCH_CHECK();
+    }
   } else if (vec4) hipLaunchKernelGGL((select_kernel<METRIC, true>), dim3((unsigned)grid), dim3(64 * SEL_WAVES), 0, s, a);
   else hipLaunchKernelGGL((select_kernel<METRIC, false>), dim3((unsigned)grid), dim3(64 * SEL_WAVES), 0, s, a);
   MMF_LAUNCH_CHECK();
@@ -371,8 +404,8 @@ static int launch_select_m(const SelectArgs& a, bool vec4, hipStream_t s) {
 
 int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
   if (p.n_rows <= 0) return MMF_OK;
-  if ((int64_t)L.lists * L.cap > SEL_MAXC) {
-    set_error("select: %d lists x %d entries exceed the per-row capacity %d", L.lists, L.cap, SEL_MAXC);
+  if ((int64_t)L.lists * L.cap + L.spill_cap > SEL_MAXC) {
+    set_error("select: %d lists x %d entries (+ %d overflow slots) exceed the per-row capacity %d", L.lists, L.cap, L.spill_cap, SEL_MAXC);
     return MMF_E_INTERNAL;
   }
   SelectArgs a{};
@@ -382,6 +415,8 @@ int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
   a.row_ids = p.row_ids; a.n_rows = p.n_rows;
   a.cand_cnt = L.cnt; a.cand_ids = L.ids; a.overflow = L.overflow; a.lists = L.lists; a.cap = L.cap;
   a.cand_keys = L.keys; a.margin = L.margin;
+  a.spill_cnt = L.spill_cnt; a.spill_ids = L.spill_ids; a.spill_cap = L.spill_cap;
+  a.pass = 0; a.defer_rows = p.defer_rows; a.defer_count = p.defer_count;
   a.out_idx = p.out_idx; a.out_val = p.out_val;
   a.fail_rows = p.fail_rows; a.fail_count = p.fail_count; a.cand_total = p.cand_total;
   const bool v4 = p.dtype == MMF_F32 && (p.d % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0) &&

@@ -103,22 +103,35 @@ def test_simtopk_fast_unnormalised_and_rect(mmf):
 
 
 def test_simtopk_fast_overflow_falls_back_to_exact(mmf):
-    # 40 exact copies of 10 rows: far more columns sit inside the bf16 margin than a list can hold,
-    # so the rows are flagged and rescanned by the exact kernel; the answer must not change.
+    # 40 exact copies of 10 rows: far more columns sit inside the f16 margin than a lane list can hold; they go to
+    # the rows' overflow lists (192 slots) and the exact re-rank sorts them out — no row needs the exact rescan
     D = np.repeat(rnd(10, 64, 3), 40, axis=0)
     idx, val, st = mmf.simtopk(dev(D), metric="neg_sq_l2", k=5, precision="fast", return_stats=True)
     ridx, rval = oracle.simtopk(D, metric="neg_sq_l2", k=5)
     assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(val.cpu().numpy(), rval)
-    assert st["precision_used"] == 2 and st["fallback_rows"] > 0 and st["overflow_rows"] == st["fallback_rows"]
-    # a tight cluster inside an otherwise random set: only the cluster's rows need the rescan
+    assert st["precision_used"] == 2 and st["fallback_rows"] == 0 and st["candidates"] >= 400 * 39
+    # 300 copies of 4 rows: more than the overflow lists hold, so the rows are flagged and rescanned by the exact
+    # kernel; the answer must not change
+    D = np.repeat(rnd(4, 64, 4), 300, axis=0)
+    idx, val, st = mmf.simtopk(dev(D), metric="neg_sq_l2", k=5, precision="fast", return_stats=True)
+    ridx, rval = oracle.simtopk(D, metric="neg_sq_l2", k=5)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(val.cpu().numpy(), rval)
+    assert st["precision_used"] == 2 and st["fallback_rows"] == 1200 and st["overflow_rows"] == st["fallback_rows"]
+    # a tight cluster inside an otherwise random set: the cluster's rows take their neighbours from the overflow lists
     X = unit_rows(3000, 128, 77).numpy()
     X[100:160] = X[100] + 1e-4 * rnd(60, 128, 78)
     ridx, rval = oracle.simtopk(X, metric="cosine", k=5)
     for splits in (1, 0):
         idx, val, st = mmf.simtopk(dev(X), metric="cosine", k=5, precision="fast", col_splits=splits, return_stats=True)
         assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(val.cpu().numpy(), rval)
-        if splits == 1:   # the 60 cluster rows (+ the few rows whose top-k touches the cluster), not the
-            assert 60 <= st["fallback_rows"] <= 120, st   # rows that only met the cluster while their threshold was low
+        assert st["fallback_rows"] == 0, st
+    # ... and a cluster larger than the overflow lists: only ITS rows are rescanned
+    X = unit_rows(3000, 128, 79).numpy()
+    X[100:400] = X[100] + 1e-4 * rnd(300, 128, 80)
+    ridx, rval = oracle.simtopk(X, metric="cosine", k=5)
+    idx, val, st = mmf.simtopk(dev(X), metric="cosine", k=5, precision="fast", col_splits=1, return_stats=True)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(val.cpu().numpy(), rval)
+    assert 300 <= st["fallback_rows"] <= 600, st     # + rows whose own top-k touches the cluster
 
 
 def test_simtopk_fast_forced_splits_and_offsets(mmf):
