@@ -452,9 +452,15 @@ struct SlotList {
         }
       }
     }
-    float c[16];
+    // k (this lane, descending) and the partner lane's list reversed form a bitonic sequence of 32: the element-wise
+    // maxima are the 16 largest of the union, the minima the 16 smallest; a 4-stage clean sorts either half.
+    float pr[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) c[e] = fmaxf(k[e], __shfl_xor(k[15 - e], 32));
+    for (int e = 0; e < 16; ++e) pr[e] = __shfl_xor(k[15 - e], 32);
+    float c[16];
+    const bool low = (CAP == 16) && (kk > 16);     // k + self in 17..20: the threshold sits in the lower half
+#pragma unroll
+    for (int e = 0; e < 16; ++e) c[e] = low ? fminf(k[e], pr[e]) : fmaxf(k[e], pr[e]);
 #pragma unroll
     for (int stride = 8; stride > 0; stride >>= 1) {
 #pragma unroll
@@ -466,10 +472,11 @@ struct SlotList {
         }
       }
     }
+    const int want = low ? (kk - 17) : (kk - 1);
     float t = kNegInf;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      if (e == kk - 1) t = c[e];
+      if (e == want) t = c[e];
     }
     raise_thr(t, margin);
     int keep = 0;

@@ -36,7 +36,7 @@ constexpr int B_CT = 32;
 #define MMF_B_CAP 15
 #endif
 constexpr int B_CAP = MMF_B_CAP;  // list entries per lane for k + self <= 11: what LDS leaves beside four 32 KiB tile stages
-constexpr int B_CAP_BIG = 16;     // ... for k + self in 12..16 (costs the fourth tile stage: TPB = 1); what a lane list
+constexpr int B_CAP_BIG = 16;     // ... for k + self in 12..20 (costs the fourth tile stage: TPB = 1); what a lane list
                                   // cannot hold goes to the row's overflow list, so the capacity bounds speed, not k
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -602,7 +602,7 @@ static int waves_for_dp(int dp) { return dp <= 512 ? 8 : 4; }   // workgroup sha
 
 int scan_bf16_supported(int64_t d, int kk, int dtype) {
   (void)dtype;
-  return (pad_dp(d) != 0 && kk <= 16) ? 1 : 0;     // 16: the merged threshold is read off a 16-wide network
+  return (pad_dp(d) != 0 && kk <= 20) ? 1 : 0;     // two 16-entry lists per query keep 14 each after a compaction
 }
 
 int scan_bf16_cap(int kk) { return kk <= B_CAP - 4 ? B_CAP : B_CAP_BIG; }

@@ -175,7 +175,7 @@ def sharded_simtopk(x_local: torch.Tensor, n_total: int, *, metric="cosine", lam
         from . import ops as _ops
         kk = k + (1 if exclude_self else 0)
         equal = (n_total % world) == 0
-        if equal and precision in ("auto", "fast", "fast_bf16") and _ops.padded_dim(x_local.shape[1]) > 0 and kk <= 16 \
+        if equal and precision in ("auto", "fast", "fast_bf16") and _ops.padded_dim(x_local.shape[1]) > 0 and kk <= 20 \
                 and x_local.dtype == torch.float32:
             out = _overlapped_simtopk(x_local.contiguous(), n_total, lo, hi, world, metric=metric, lam=lam, k=k,
                                       exclude_self=exclude_self, operand="bf16" if precision == "fast_bf16" else "f16",

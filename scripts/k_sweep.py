@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 import multimodal_fusion_amd as mmf
 from bench import make_rows
 X = make_rows(0, 65536, 512, torch.device('cuda'))
-for k in (5, 11, 15, 16):
+for k in (5, 11, 15, 16, 19, 20):
     for it in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         i, v, st = mmf.simtopk(X, metric='cosine', k=k, return_stats=True, profile=True)

@@ -33,12 +33,12 @@ def test_determinism_and_precision_invariance(mmf):
 def test_k_prefix_and_unnormalised_metrics(mmf, metric):
     X = make(6000, 200, 2, unit=False) * (0.05 if metric == "rbf" else 1.0)
     prev = None
-    for k in (1, 2, 5, 7, 10, 11, 15):
+    for k in (1, 2, 5, 7, 10, 11, 15, 16, 19):
         idx, val = mmf.simtopk(X, metric=metric, lam=0.5, k=k)
         if prev is not None:
             assert torch.equal(idx[:, :prev[0].shape[1]], prev[0]) and torch.equal(val[:, :prev[1].shape[1]], prev[1])
         prev = (idx, val)
-    ex = mmf.simtopk(X, metric=metric, lam=0.5, k=15, precision="exact")   # k + self <= 11: 15-entry lists; 12..16: 16-entry lists
+    ex = mmf.simtopk(X, metric=metric, lam=0.5, k=19, precision="exact")   # k + self <= 11: 15-entry lists; 12..20: 16-entry lists
     assert torch.equal(ex[0], prev[0])
     if metric != "rbf":
         assert torch.equal(ex[1], prev[1])
@@ -97,7 +97,7 @@ def test_random_configurations_against_the_oracle(mmf):
         n = int(rng.randint(1, 700))
         m = int(rng.randint(40, 3000))
         d = int(rng.choice([1, 2, 3, 7, 16, 31, 64, 100, 129, 255, 256, 300, 512, 513, 777, 1024, 1100]))
-        k = int(rng.randint(1, 18))
+        k = int(rng.randint(1, 23))
         metric = metrics[case % 4]
         dt = dtypes[(case // 4) % 3]
         excl = bool(rng.randint(0, 2))
