@@ -186,7 +186,11 @@ def test_paneled_scan_equals_single_call(mmf, metric, S, splits):
     of every rank, rank-major) == the rows of the single-call result, bit for bit."""
     N, d, P, k = 16384, 200, 4, 6
     X = make(N, d, 41) * (1.0 if metric == "cosine" else (0.05 if metric == "rbf" else 3.0))
+    X[300:360] = X[300]                       # 60 exact copies: their columns overflow the lane lists into the rows'
+    X[5000:5060] = X[300]                     # overflow lists, whose ids go through the panel -> global column map
     full_i, full_v = mmf.simtopk(X, metric=metric, lam=0.5, k=k)
+    ex_i, _ = mmf.simtopk(X, metric=metric, lam=0.5, k=k, precision="exact")
+    assert torch.equal(full_i, ex_i)
     ops = mmf.ops
     dp = ops.padded_dim(d)
     rows = N // P
