@@ -70,7 +70,8 @@ extern "C" {
                              else EXACT (any d, k + self <= 28)                                       */
 #define MMF_PREC_EXACT 1  /* v_mfma_f32_32x32x2_f32 scan, canonical keys in-kernel           */
 #define MMF_PREC_FAST  2  /* f16 MFMA scan (rows scaled by an exact power of two) with a proven error
-                             margin + exact f32 re-rank; overflowed rows are rescanned exactly      */
+                             margin + exact f32 re-rank; columns inside a row's margin that do not fit its
+                             lists go to a per-row overflow list, rows that exhaust it are rescanned exactly */
 #define MMF_PREC_FAST_BF16 3 /* same with bf16 operands: 8x larger rounding residual, wider margin    */
 
 int         mmf_version(void);
