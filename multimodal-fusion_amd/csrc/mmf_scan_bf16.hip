@@ -93,12 +93,24 @@ __global__ __launch_bounds__(256) void prep_half_kernel(PrepArgs a) {
     const float sc = a.scal[row];
     float s_z = 0.f, s_r = 0.f, s_u = 0.f;
     const bool vec = (a.dtype == MMF_F32) && ((a.d & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
+    const bool vec16 = (a.dtype != MMF_F32) && ((a.d & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 7) == 0);
     for (int k4 = lane * 4; k4 < a.dp; k4 += 256) {       // 4 consecutive k per lane: 16 B in, 8 B out
       float u4[4] = {0.f, 0.f, 0.f, 0.f};
       if (vec) {
         if (k4 < a.d) {
           const f32x4 x4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.X) + row * a.d + k4);
           u4[0] = x4[0]; u4[1] = x4[1]; u4[2] = x4[2]; u4[3] = x4[3];
+        }
+      } else if (vec16) {                                   // bf16 / f16 rows: 8 bytes per lane, exact upcasts
+        if (k4 < a.d) {
+          const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(a.X) + row * a.d + k4);
+          if (a.dtype == MMF_BF16) {
+            u4[0] = __uint_as_float(h.x << 16); u4[1] = __uint_as_float(h.x & 0xffff0000u);
+            u4[2] = __uint_as_float(h.y << 16); u4[3] = __uint_as_float(h.y & 0xffff0000u);
+          } else {
+            u4[0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(h.x & 0xffffu)); u4[1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(h.x >> 16));
+            u4[2] = (float)__builtin_bit_cast(_Float16, (uint16_t)(h.y & 0xffffu)); u4[3] = (float)__builtin_bit_cast(_Float16, (uint16_t)(h.y >> 16));
+          }
         }
       } else {
 #pragma unroll

@@ -233,7 +233,26 @@ constexpr int SG = 16;
 constexpr int SC = 128;
 constexpr int SLD = SC + 4;
 
-template <int METRIC>
+// four consecutive elements of a row as f32 (exact upcasts): 16 bytes of f32, or 8 bytes of bf16 / f16
+template <int DT>
+__device__ __forceinline__ f32x4 ld4_row(const void* base, int64_t elem) {
+  if constexpr (DT == MMF_F32) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + elem);
+  } else {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem);
+    f32x4 v;
+    if constexpr (DT == MMF_BF16) {
+      v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+      v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    } else {
+      v[0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u.x & 0xffffu)); v[1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u.x >> 16));
+      v[2] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u.y & 0xffffu)); v[3] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u.y >> 16));
+    }
+    return v;
+  }
+}
+
+template <int METRIC, int DT>
 __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArgs a) {
   // dynamic LDS: per wave [maxc] keys + [maxc] ids (maxc = lists * cap rounded up to 64), then the tiles
   extern __shared__ __attribute__((aligned(16))) char sel_smem[];
@@ -258,8 +277,8 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
   const int64_t row = a.row_ids ? (int64_t)a.row_ids[pos] : pos;
   float* key = skey_base + wave * maxc;
   uint32_t* id = sid_base + wave * maxc;
-  const float* X = reinterpret_cast<const float*>(a.X);
-  const float* Y = reinterpret_cast<const float*>(a.Y);
+  const void* X = a.X;
+  const void* Y = a.Y;
 
   bool failed = a.overflow[pos] != 0;
   const bool was_overflow = failed;
@@ -290,7 +309,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
       auto gload = [&](int64_t k0) {
         const int kc = (a.d - k0 < SC) ? (int)(a.d - k0) : SC;
         xv = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (hl == 0 && 4 * ll < kc) xv = *reinterpret_cast<const f32x4*>(X + row * a.d + k0 + 4 * ll);
+        if (hl == 0 && 4 * ll < kc) xv = ld4_row<DT>(X, row * a.d + k0 + 4 * ll);
 #pragma unroll
         for (int p = 0; p < SG / 2; ++p) {
           const int cnd = 2 * p + hl;
@@ -298,7 +317,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
           if (cnd < ng && 4 * ll < kc) {
             uint32_t j = id[g0 + cnd];
             if ((int64_t)j >= a.m) j = 0;
-            yv[p] = *reinterpret_cast<const f32x4*>(Y + (int64_t)j * a.d + k0 + 4 * ll);
+            yv[p] = ld4_row<DT>(Y, (int64_t)j * a.d + k0 + 4 * ll);
           }
         }
       };
@@ -380,10 +399,11 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
 }
 
 template <int METRIC>
-static int launch_select_m(const SelectArgs& a, bool vec4, hipStream_t s) {
+static int launch_select_m(const SelectArgs& a, bool vec4, bool staged16, hipStream_t s) {
   const int64_t grid = (a.n_rows + SEL_WAVES - 1) / SEL_WAVES;
-  if (vec4 && a.d >= 64) {
-    auto kern = select_staged_kernel<METRIC>;
+  if ((vec4 || staged16) && a.d >= 64) {
+    auto kern = a.dtype == MMF_F32 ? select_staged_kernel<METRIC, MMF_F32>
+                : (a.dtype == MMF_BF16 ? select_staged_kernel<METRIC, MMF_BF16> : select_staged_kernel<METRIC, MMF_F16>);
     const bool two = a.spill_cnt != nullptr && a.defer_rows != nullptr && a.row_ids == nullptr;
     for (int pass = 0; pass < (two ? 2 : 1); ++pass) {
       SelectArgs b = a;
@@ -421,11 +441,14 @@ int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
   a.fail_rows = p.fail_rows; a.fail_count = p.fail_count; a.cand_total = p.cand_total;
   const bool v4 = p.dtype == MMF_F32 && (p.d % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0) &&
                   ((reinterpret_cast<uintptr_t>(p.Y) & 15) == 0);
+  // 16-bit rows take the same staged kernel with 8-byte loads
+  const bool s16 = p.dtype != MMF_F32 && (p.d % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 7) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(p.Y) & 7) == 0);
   switch (p.metric) {
-    case MMF_DOT: return launch_select_m<MMF_DOT>(a, v4, s);
-    case MMF_COSINE: return launch_select_m<MMF_COSINE>(a, v4, s);
-    case MMF_NEG_SQ_L2: return launch_select_m<MMF_NEG_SQ_L2>(a, v4, s);
-    case MMF_RBF: return launch_select_m<MMF_RBF>(a, v4, s);
+    case MMF_DOT: return launch_select_m<MMF_DOT>(a, v4, s16, s);
+    case MMF_COSINE: return launch_select_m<MMF_COSINE>(a, v4, s16, s);
+    case MMF_NEG_SQ_L2: return launch_select_m<MMF_NEG_SQ_L2>(a, v4, s16, s);
+    case MMF_RBF: return launch_select_m<MMF_RBF>(a, v4, s16, s);
   }
   set_error("select: unsupported metric %d", p.metric);
   return MMF_E_INVALID;
