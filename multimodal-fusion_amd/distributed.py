@@ -3,8 +3,8 @@
 (RCCL over xGMI when the backend is "nccl"); each rank then scans every column for its own rows with the
 global row/column offsets.  No all-to-all: outputs are row-owned and stay sharded unless `gather_output=True`.
 
-Two drivers: the simple one (one all-gather of the f32 shard, then mmf_simtopk) and the pipelined one used
-for equal f32 shards (16-bit operands exchanged in chunks under the scan, f32 rows under all of it).
+Two drivers: the simple one (one all-gather of the feature shard, then mmf_simtopk) and the pipelined one used
+for equal shards (16-bit operands exchanged in chunks under the scan, the feature rows under all of it).
 
 The reference has no distributed code; correctness here means
 sharded(P) == unsharded, bit for bit, which tests/test_distributed_cpu.py checks with gloo and the
@@ -176,7 +176,7 @@ def sharded_simtopk(x_local: torch.Tensor, n_total: int, *, metric="cosine", lam
         kk = k + (1 if exclude_self else 0)
         equal = (n_total % world) == 0
         if equal and precision in ("auto", "fast", "fast_bf16") and _ops.padded_dim(x_local.shape[1]) > 0 and kk <= 20 \
-                and x_local.dtype == torch.float32:
+                and x_local.dtype in (torch.float32, torch.float16, torch.bfloat16):
             out = _overlapped_simtopk(x_local.contiguous(), n_total, lo, hi, world, metric=metric, lam=lam, k=k,
                                       exclude_self=exclude_self, operand="bf16" if precision == "fast_bf16" else "f16",
                                       group=group, return_stats=return_stats, chunks=chunks, col_splits=col_splits)

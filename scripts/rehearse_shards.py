@@ -10,8 +10,9 @@ torch.cuda.set_device(0)
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 dev = torch.device("cuda", 0)
-for N, d, metric in ((16384, 512, "cosine"), (8192, 128, "neg_sq_l2")):
-    X = make_rows(0, N, d, dev) * (1.0 if metric == "cosine" else 2.5)
+for N, d, metric, dt in ((16384, 512, "cosine", torch.float32), (8192, 128, "neg_sq_l2", torch.float32),
+                         (8192, 256, "cosine", torch.float16), (8192, 1024, "dot", torch.bfloat16)):
+    X = (make_rows(0, N, d, dev) * (1.0 if metric == "cosine" else 2.5)).to(dt)
     ref_i, ref_v = mmf.simtopk(X, metric=metric, k=5)
     lo, hi = dmod.shard_bounds(N, world, rank)
     for overlap in (True, False):
