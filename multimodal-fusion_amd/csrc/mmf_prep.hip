@@ -51,7 +51,27 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void row_scalars_kernel(const void
 // wave instruction), ds_write_b128 / ds_read_b128 and a 68-float row stride: for a b128 access lane r
 // touches the 16-byte slot (17 r) mod 16, so the 16 lanes of a group are conflict-free.
 constexpr int PV_LD = 68;
-__global__ __launch_bounds__(64 * PREP_WAVES) void row_scalars_vec_kernel(const float* __restrict__ X, int64_t n,
+// DT: MMF_F32 (16-byte loads) or MMF_BF16 / MMF_F16 (8-byte loads, exact upcasts)
+template <int DT>
+__device__ __forceinline__ f32x4 ld4_any(const void* base, int64_t elem) {
+  if constexpr (DT == MMF_F32) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + elem);
+  } else {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem);
+    f32x4 v;
+    if constexpr (DT == MMF_BF16) {
+      v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+      v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    } else {
+      v[0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u.x & 0xffffu)); v[1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u.x >> 16));
+      v[2] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u.y & 0xffffu)); v[3] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u.y >> 16));
+    }
+    return v;
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(64 * PREP_WAVES) void row_scalars_vec_kernel(const void* __restrict__ X, int64_t n,
                                                                             int64_t d, int metric,
                                                                             float* __restrict__ out,
                                                                             uint32_t* __restrict__ max_n) {
@@ -69,7 +89,7 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void row_scalars_vec_kernel(const 
       const int64_t row = row0 + 4 * i + lr;
       const int64_t k = k0 + lk;
       v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (row < n && k < d) v[i] = *reinterpret_cast<const f32x4*>(X + row * d + k);
+      if (row < n && k < d) v[i] = ld4_any<DT>(X, row * d + k);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(&tile[wave][4 * i + lr][lk]) = v[i];
@@ -99,9 +119,10 @@ int launch_row_scalars(const void* X, int64_t n, int64_t d, int dtype, int metri
   if (n <= 0) return MMF_OK;
   const int64_t rows_per_block = 64 * PREP_WAVES;
   const int64_t grid = (n + rows_per_block - 1) / rows_per_block;
-  if (dtype == MMF_F32 && (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0)) {
-    hipLaunchKernelGGL(row_scalars_vec_kernel, dim3((unsigned)grid), dim3(64 * PREP_WAVES), 0, s,
-                       reinterpret_cast<const float*>(X), n, d, metric, out, max_n);
+  if ((d % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & (dtype == MMF_F32 ? 15 : 7)) == 0)) {
+    if (dtype == MMF_F32) hipLaunchKernelGGL(row_scalars_vec_kernel<MMF_F32>, dim3((unsigned)grid), dim3(64 * PREP_WAVES), 0, s, X, n, d, metric, out, max_n);
+    else if (dtype == MMF_BF16) hipLaunchKernelGGL(row_scalars_vec_kernel<MMF_BF16>, dim3((unsigned)grid), dim3(64 * PREP_WAVES), 0, s, X, n, d, metric, out, max_n);
+    else hipLaunchKernelGGL(row_scalars_vec_kernel<MMF_F16>, dim3((unsigned)grid), dim3(64 * PREP_WAVES), 0, s, X, n, d, metric, out, max_n);
     MMF_LAUNCH_CHECK();
     return MMF_OK;
   }
