@@ -266,6 +266,20 @@ int mmf_threshold_edges(const float* K, int64_t n, float threshold,
                         int64_t* edge_index, float* edge_w, int64_t capacity,
                         int64_t* out_count, int device_id, void* hip_stream);
 
+/*
+ * The same two steps for an N whose combined similarity K = K_h * K_g ([n,n] f32) does not fit in
+ * memory: K is recomputed from (F, P) in row panels of `panel_rows` rows (0 = about 1 GiB per panel) — four sweeps
+ * for the median (one per radix byte), one sweep per call of the edge builder (capacity 0 counts, then fill).
+ * Results are those of mmf_sim_dense_combined + mmf_offdiag_lower_median / mmf_threshold_edges, bit for bit.
+ */
+int mmf_combined_offdiag_median(const float* F, const float* P, int64_t n, int64_t d, int64_t dp,
+                                float lambda_h, float lambda_g, int64_t panel_rows, float* out_median,
+                                int device_id, void* hip_stream);
+int mmf_combined_threshold_edges(const float* F, const float* P, int64_t n, int64_t d, int64_t dp,
+                                 float lambda_h, float lambda_g, float threshold, int64_t panel_rows,
+                                 int64_t* edge_index, float* edge_w, int64_t capacity, int64_t* out_count,
+                                 int device_id, void* hip_stream);
+
 /* Release the library's cached per-device workspaces (they are grow-only otherwise). */
 int mmf_release_workspaces(void);
 

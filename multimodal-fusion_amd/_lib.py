@@ -45,7 +45,7 @@ _lib = None
 
 EXPORTS = ["mmf_version", "mmf_last_error", "mmf_simtopk", "mmf_simtopk_ex", "mmf_row_scalars", "mmf_prep_rows",
            "mmf_simtopk_prepared", "mmf_simtopk_panels", "mmf_padded_dim", "mmf_topk_merge", "mmf_edge_cosine",
-           "mmf_sim_dense", "mmf_sim_dense_combined", "mmf_offdiag_lower_median", "mmf_threshold_edges",
+           "mmf_sim_dense", "mmf_sim_dense_combined", "mmf_offdiag_lower_median", "mmf_threshold_edges", "mmf_combined_offdiag_median", "mmf_combined_threshold_edges",
            "mmf_release_workspaces"]
 
 
@@ -79,6 +79,8 @@ def lib() -> ctypes.CDLL:
     L.mmf_sim_dense_combined.argtypes = [vp, vp, i64, i64, i64, f32, f32, vp, ci, vp]
     L.mmf_offdiag_lower_median.argtypes = [vp, i64, vp, ci, vp]
     L.mmf_threshold_edges.argtypes = [vp, i64, f32, vp, vp, i64, vp, ci, vp]
+    L.mmf_combined_offdiag_median.argtypes = [vp, vp, i64, i64, i64, f32, f32, i64, vp, ci, vp]
+    L.mmf_combined_threshold_edges.argtypes = [vp, vp, i64, i64, i64, f32, f32, f32, i64, vp, vp, i64, vp, ci, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ("mmf_last_error", "mmf_padded_dim"):

@@ -5,7 +5,8 @@ defaults and error behaviour; the arithmetic runs in the gfx950 kernels behind i
     compute_morphological_similarity  :17-54    mmf_sim_dense(MMF_RBF)         (f32 MFMA, canonical chain)
     compute_spatial_similarity        :57-86    mmf_sim_dense(MMF_RBF) on the 2-/3-D positions
     compute_combined_similarity       :88-124   mmf_sim_dense_combined         (one pass, no K_h/K_g temporaries)
-    build_weighted_hypergraph         :126-212  mmf_offdiag_lower_median + mmf_threshold_edges
+    build_weighted_hypergraph         :126-212  mmf_offdiag_lower_median + mmf_threshold_edges (materialised K), or
+                                                mmf_combined_offdiag_median + mmf_combined_threshold_edges (large N)
     mean_pool_with_similarity         :214-238  torch.mean (trivial, a5)
     build_hypergraph_data             :240-306  packaging
 """
@@ -17,6 +18,11 @@ import torch
 
 from .. import ops
 from ._common import compute_device, f32_ceil, result_device_like_kernel, to_gpu
+
+# build_weighted_hypergraph keeps K = K_h * K_g in HBM up to this many bytes; beyond it the median and the edges are
+# computed from K recomputed in row panels of PANEL_ROWS rows (0 = about 1 GiB per panel).  Same result either way.
+STREAM_BYTES = 32 << 30
+PANEL_ROWS = 0
 
 
 def compute_morphological_similarity(features: torch.Tensor, lambda_h: float = 1.0) -> torch.Tensor:
@@ -49,6 +55,18 @@ def build_weighted_hypergraph(features: torch.Tensor, positions: torch.Tensor, l
     default ratio None raises TypeError at `median * None` (:188)."""
     out_dev = result_device_like_kernel(features, device)
     dev = compute_device(features, positions) if out_dev.type != "cuda" else out_dev
+    N = features.shape[0]
+    if N * N * 4 > STREAM_BYTES:
+        # K would not be worth (or possible) keeping: recompute it in row panels — same median, same edges
+        F, Pz = to_gpu(features, dev), to_gpu(positions, dev)
+        if N <= 1:
+            raise ValueError(f"Number of nodes must be greater than 1, got N={N}. "
+                             f"Hypergraph construction requires at least 2 nodes.")
+        median_sim = ops.combined_offdiag_median(F, Pz, float(lambda_h), float(lambda_g), PANEL_ROWS).item()
+        threshold = median_sim * threshold_median_ratio
+        edge_index, edge_weights = ops.combined_threshold_edges(F, Pz, f32_ceil(threshold), float(lambda_h), float(lambda_g),
+                                                                PANEL_ROWS)
+        return edge_index.to(out_dev).contiguous(), edge_weights.to(out_dev)
     K = ops.sim_dense_combined(to_gpu(features, dev), to_gpu(positions, dev), float(lambda_h), float(lambda_g))
     N = K.shape[0]
     if N <= 1:

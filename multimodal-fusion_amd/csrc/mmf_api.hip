@@ -732,7 +732,7 @@ int mmf_sim_dense_combined(const float* F, const float* P, int64_t n, int64_t d,
   MMF_TRY(get_workspace(device_id, s, ws_bytes(n, 4), &ws));
   float* nf = ws.take<float>(n);
   MMF_TRY(launch_row_scalars(F, n, d, MMF_F32, MMF_RBF, nf, nullptr, s));
-  return launch_sim_dense_combined(F, P, n, d, dp, lambda_h, lambda_g, nf, out, s);
+  return launch_sim_dense_combined(F, P, n, d, dp, lambda_h, lambda_g, nf, 0, n, out, s);
 }
 
 int mmf_offdiag_lower_median(const float* K, int64_t n, float* out_median, int device_id, void* hip_stream) {
@@ -755,13 +755,78 @@ int mmf_threshold_edges(const float* K, int64_t n, float threshold, int64_t* edg
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   DeviceGuard guard(device_id);
   if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
-  if (n == 0) { MMF_HIP(hipMemsetAsync(out_count, 0, 8, s)); return MMF_OK; }
+  MMF_HIP(hipMemsetAsync(out_count, 0, 8, s));
+  if (n == 0) return MMF_OK;
   if (!K || (capacity > 0 && (!edge_index || !edge_w))) { set_error("threshold_edges: NULL pointer"); return MMF_E_INVALID; }
   const size_t rows_u32 = (size_t)n * 2 + 64;
   Workspace ws;
   MMF_TRY(get_workspace(device_id, s, ws_bytes(rows_u32, 8), &ws));
   return launch_threshold_edges(K, n, threshold, edge_index, edge_w, capacity, out_count,
                                 reinterpret_cast<uint32_t*>(ws.take<uint64_t>(rows_u32)), rows_u32 * 2, s);
+}
+
+// ---- the same two steps for an N whose K = K_h * K_g does not fit: K is recomputed in row panels -----------------
+static int64_t pick_panel_rows(int64_t n, int64_t panel_rows) {
+  if (panel_rows <= 0) panel_rows = (int64_t(1) << 30) / (4 * n);     // about 1 GiB of f32 per panel
+  if (panel_rows < 128) panel_rows = 128;
+  if (panel_rows > n) panel_rows = n;
+  return panel_rows;
+}
+
+int mmf_combined_offdiag_median(const float* F, const float* P, int64_t n, int64_t d, int64_t dp, float lambda_h,
+                                float lambda_g, int64_t panel_rows, float* out_median, int device_id, void* hip_stream) {
+  MMF_TRY(check_common(F, n, n, d, MMF_F32, device_id));
+  if (dp < 1 || n < 2) { set_error("combined_offdiag_median: need dp >= 1 and n >= 2"); return MMF_E_INVALID; }
+  if (!P || !out_median) { set_error("combined_offdiag_median: NULL pointer"); return MMF_E_INVALID; }
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  const int64_t R = pick_panel_rows(n, panel_rows);
+  Workspace ws;
+  MMF_TRY(get_workspace(device_id, s, ws_bytes(n, 4) + ws_bytes((size_t)R * n, 4) + ws_bytes(median_state_bytes(), 1), &ws));
+  float* nf = ws.take<float>(n);
+  float* Kp = ws.take<float>((size_t)R * n);
+  void* st = ws.take<char>(median_state_bytes());
+  MMF_TRY(launch_row_scalars(F, n, d, MMF_F32, MMF_RBF, nf, nullptr, s));
+  MMF_TRY(launch_median_begin(st, n, s));
+  for (int pass = 0; pass < 4; ++pass) {             // one sweep over the recomputed matrix per radix byte
+    for (int64_t r0 = 0; r0 < n; r0 += R) {
+      const int64_t rows = (n - r0 < R) ? (n - r0) : R;
+      MMF_TRY(launch_sim_dense_combined(F, P, n, d, dp, lambda_h, lambda_g, nf, r0, rows, Kp, s));
+      MMF_TRY(launch_median_accumulate(Kp, n, r0, rows, st, pass, s));
+    }
+    MMF_TRY(launch_median_next(st, pass, out_median, s));
+  }
+  return MMF_OK;
+}
+
+int mmf_combined_threshold_edges(const float* F, const float* P, int64_t n, int64_t d, int64_t dp, float lambda_h,
+                                 float lambda_g, float threshold, int64_t panel_rows, int64_t* edge_index, float* edge_w,
+                                 int64_t capacity, int64_t* out_count, int device_id, void* hip_stream) {
+  MMF_TRY(check_common(F, n, n, d, MMF_F32, device_id));
+  if (dp < 1 || capacity < 0) { set_error("combined_threshold_edges: bad dp / capacity"); return MMF_E_INVALID; }
+  if (!out_count) { set_error("combined_threshold_edges: NULL out_count"); return MMF_E_INVALID; }
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  MMF_HIP(hipMemsetAsync(out_count, 0, 8, s));
+  if (n == 0) return MMF_OK;
+  if (!P || (capacity > 0 && (!edge_index || !edge_w))) { set_error("combined_threshold_edges: NULL pointer"); return MMF_E_INVALID; }
+  const int64_t R = pick_panel_rows(n, panel_rows);
+  const size_t rows_u32 = (size_t)R * 2 + 64;
+  Workspace ws;
+  MMF_TRY(get_workspace(device_id, s, ws_bytes(n, 4) + ws_bytes((size_t)R * n, 4) + ws_bytes(rows_u32, 8), &ws));
+  float* nf = ws.take<float>(n);
+  float* Kp = ws.take<float>((size_t)R * n);
+  uint32_t* scratch = reinterpret_cast<uint32_t*>(ws.take<uint64_t>(rows_u32));
+  MMF_TRY(launch_row_scalars(F, n, d, MMF_F32, MMF_RBF, nf, nullptr, s));
+  for (int64_t r0 = 0; r0 < n; r0 += R) {            // panels in row order: the running count keeps the edges row-major
+    const int64_t rows = (n - r0 < R) ? (n - r0) : R;
+    MMF_TRY(launch_sim_dense_combined(F, P, n, d, dp, lambda_h, lambda_g, nf, r0, rows, Kp, s));
+    MMF_TRY(launch_threshold_edges_panel(Kp, n, r0, rows, threshold, edge_index, edge_index ? edge_index + capacity : nullptr,
+                                         edge_w, capacity, out_count, scratch, rows_u32 * 2, s));
+  }
+  return MMF_OK;
 }
 
 }  // extern "C"

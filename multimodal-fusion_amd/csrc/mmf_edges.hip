@@ -36,8 +36,9 @@ __global__ void median_init_kernel(MedianState* st, unsigned long long rank) {
 // A workgroup walks whole rows (no per-element division), 16 bytes per lane when n % 4 == 0.  Similarities are
 // concentrated — in the first passes nearly every entry lands in one or two bins — so a lane counts runs of equal
 // bins in a register and touches the LDS histogram only when the bin changes.
-__global__ __launch_bounds__(256) void median_hist_kernel(const float* __restrict__ K, int64_t n, MedianState* st,
-                                                          int shift) {
+// K: rows [row0, row0 + rows) of the n x n matrix (row0 = 0, rows = n: all of it).
+__global__ __launch_bounds__(256) void median_hist_kernel(const float* __restrict__ K, int64_t n, int64_t row0, int64_t rows,
+                                                          MedianState* st, int shift) {
   __shared__ unsigned int lh[256];
   lh[threadIdx.x] = 0u;
   __syncthreads();
@@ -54,8 +55,9 @@ __global__ __launch_bounds__(256) void median_hist_kernel(const float* __restric
     cur = bin; run = 1;
   };
   const bool vec = ((n & 3) == 0) && ((reinterpret_cast<uintptr_t>(K) & 15) == 0);
-  for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
-    const float* row = K + i * n;
+  for (int64_t li = blockIdx.x; li < rows; li += gridDim.x) {
+    const float* row = K + li * n;
+    const int64_t i = row0 + li;                       // global row: its diagonal entry is skipped
     if (vec) {
       for (int64_t j = (int64_t)threadIdx.x * 4; j < n; j += 1024) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(row + j);
@@ -92,28 +94,46 @@ __global__ void median_pick_kernel(MedianState* st, int shift, float* out) {
 
 int launch_offdiag_lower_median(const float* K, int64_t n, float* out, uint32_t* scratch, hipStream_t s) {
   MedianState* st = reinterpret_cast<MedianState*>(scratch);
-  const unsigned long long cnt = (unsigned long long)n * (unsigned long long)(n - 1);
-  hipLaunchKernelGGL(median_init_kernel, dim3(1), dim3(256), 0, s, st, (cnt - 1) / 2);
-  MMF_LAUNCH_CHECK();
-  int64_t grid = n < 4096 ? n : 4096;          // workgroups take whole rows
-  if (grid < 1) grid = 1;
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    hipLaunchKernelGGL(median_hist_kernel, dim3((unsigned)grid), dim3(256), 0, s, K, n, st, shift);
-    MMF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(median_pick_kernel, dim3(1), dim3(256), 0, s, st, shift, out);
-    MMF_LAUNCH_CHECK();
+  MMF_TRY(launch_median_begin(st, n, s));
+  for (int pass = 0; pass < 4; ++pass) {
+    MMF_TRY(launch_median_accumulate(K, n, 0, n, st, pass, s));
+    MMF_TRY(launch_median_next(st, pass, out, s));
   }
+  return MMF_OK;
+}
+
+// The same radix select in pieces, for matrices that are recomputed panel by panel instead of stored:
+// begin; then for pass 0..3 { accumulate every panel; next }.  `out` is written by next(pass 3).
+size_t median_state_bytes() { return sizeof(MedianState); }
+int launch_median_begin(void* state, int64_t n, hipStream_t s) {
+  const unsigned long long cnt = (unsigned long long)n * (unsigned long long)(n - 1);
+  hipLaunchKernelGGL(median_init_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<MedianState*>(state), (cnt - 1) / 2);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+int launch_median_accumulate(const float* K, int64_t n, int64_t row0, int64_t rows, void* state, int pass, hipStream_t s) {
+  if (rows <= 0) return MMF_OK;
+  int64_t grid = rows < 4096 ? rows : 4096;          // workgroups take whole rows
+  hipLaunchKernelGGL(median_hist_kernel, dim3((unsigned)grid), dim3(256), 0, s, K, n, row0, rows,
+                     reinterpret_cast<MedianState*>(state), 24 - 8 * pass);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+int launch_median_next(void* state, int pass, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(median_pick_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<MedianState*>(state), 24 - 8 * pass, out);
+  MMF_LAUNCH_CHECK();
   return MMF_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
 // threshold edges
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void thr_count_kernel(const float* __restrict__ K, int64_t n, float thr,
+// K: `rows` rows of n entries each (a panel of the square matrix, or all of it)
+__global__ __launch_bounds__(256) void thr_count_kernel(const float* __restrict__ K, int64_t n, int64_t rows, float thr,
                                                         uint32_t* __restrict__ row_cnt) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= n) return;
+  if (row >= rows) return;
   uint32_t c = 0;
   for (int64_t j = lane; j < n; j += 64) c += (K[row * n + j] < thr) ? 0u : 1u;  // skipped iff K < thr (:198)
 #pragma unroll
@@ -121,10 +141,13 @@ __global__ __launch_bounds__(256) void thr_count_kernel(const float* __restrict_
   if (lane == 0) row_cnt[row] = c;
 }
 
+// Exclusive offsets of the rows, starting at the edges already counted (*out_count on entry: 0 for a whole matrix,
+// the running total when panels are processed one after the other); *out_count is advanced by this panel's edges.
 __global__ __launch_bounds__(1024) void thr_scan_kernel(const uint32_t* __restrict__ row_cnt, int64_t n,
                                                         unsigned long long* __restrict__ row_off,
                                                         int64_t* __restrict__ out_count) {
   __shared__ unsigned long long part[1024];
+  const unsigned long long base = (unsigned long long)*out_count;
   const int t = threadIdx.x;
   const int64_t per = (n + 1023) / 1024;
   const int64_t b = (int64_t)t * per;
@@ -140,18 +163,19 @@ __global__ __launch_bounds__(1024) void thr_scan_kernel(const uint32_t* __restri
     part[t] += v;
     __syncthreads();
   }
-  unsigned long long run = (t == 0) ? 0ull : part[t - 1];
+  unsigned long long run = base + ((t == 0) ? 0ull : part[t - 1]);
   for (int64_t i = b; i < e; ++i) { row_off[i] = run; run += row_cnt[i]; }
-  if (t == 1023) *out_count = (int64_t)part[1023];
+  __syncthreads();                                   // everybody has read the base
+  if (t == 1023) *out_count = (int64_t)(base + part[1023]);
 }
 
-__global__ __launch_bounds__(256) void thr_fill_kernel(const float* __restrict__ K, int64_t n, float thr,
-                                                       const unsigned long long* __restrict__ row_off,
-                                                       int64_t* __restrict__ ei, float* __restrict__ ew,
-                                                       int64_t capacity) {
+__global__ __launch_bounds__(256) void thr_fill_kernel(const float* __restrict__ K, int64_t n, int64_t row0, int64_t rows,
+                                                       float thr, const unsigned long long* __restrict__ row_off,
+                                                       int64_t* __restrict__ ei_row, int64_t* __restrict__ ei_col,
+                                                       float* __restrict__ ew, int64_t capacity) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= n) return;
+  if (row >= rows) return;
   unsigned long long pos = row_off[row];
   for (int64_t j0 = 0; j0 < n; j0 += 64) {
     const int64_t j = j0 + lane;
@@ -160,27 +184,35 @@ __global__ __launch_bounds__(256) void thr_fill_kernel(const float* __restrict__
     const unsigned long long mask = __ballot(keep);
     if (keep) {
       const unsigned long long p = pos + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
-      if ((int64_t)p < capacity) { ei[p] = row; ei[capacity + p] = j; ew[p] = v; }
+      if ((int64_t)p < capacity) { ei_row[p] = row0 + row; ei_col[p] = j; ew[p] = v; }
     }
     pos += (unsigned long long)__popcll(mask);
   }
 }
 
-int launch_threshold_edges(const float* K, int64_t n, float thr, int64_t* ei, float* ew, int64_t capacity,
-                           int64_t* out_count, uint32_t* scratch, size_t scratch_u32, hipStream_t s) {
-  if ((size_t)(2 * (n + 1) + n) > scratch_u32) { set_error("threshold_edges: scratch too small"); return MMF_E_INTERNAL; }
+// K: rows [row0, row0 + rows) of the n x n matrix.  Edges are written to (ei_row, ei_col, ew)[0 .. count), row-major.
+int launch_threshold_edges_panel(const float* K, int64_t n, int64_t row0, int64_t rows, float thr, int64_t* ei_row,
+                                 int64_t* ei_col, float* ew, int64_t capacity, int64_t* out_count, uint32_t* scratch,
+                                 size_t scratch_u32, hipStream_t s) {
+  if ((size_t)(2 * (rows + 1) + rows) > scratch_u32) { set_error("threshold_edges: scratch too small"); return MMF_E_INTERNAL; }
   unsigned long long* row_off = reinterpret_cast<unsigned long long*>(scratch);
-  uint32_t* row_cnt = scratch + 2 * (n + 1);
-  const unsigned grid = (unsigned)((n + 3) / 4);
-  hipLaunchKernelGGL(thr_count_kernel, dim3(grid), dim3(256), 0, s, K, n, thr, row_cnt);
+  uint32_t* row_cnt = scratch + 2 * (rows + 1);
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  hipLaunchKernelGGL(thr_count_kernel, dim3(grid), dim3(256), 0, s, K, n, rows, thr, row_cnt);
   MMF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(thr_scan_kernel, dim3(1), dim3(1024), 0, s, row_cnt, n, row_off, out_count);
+  hipLaunchKernelGGL(thr_scan_kernel, dim3(1), dim3(1024), 0, s, row_cnt, rows, row_off, out_count);
   MMF_LAUNCH_CHECK();
   if (capacity > 0) {
-    hipLaunchKernelGGL(thr_fill_kernel, dim3(grid), dim3(256), 0, s, K, n, thr, row_off, ei, ew, capacity);
+    hipLaunchKernelGGL(thr_fill_kernel, dim3(grid), dim3(256), 0, s, K, n, row0, rows, thr, row_off, ei_row, ei_col, ew, capacity);
     MMF_LAUNCH_CHECK();
   }
   return MMF_OK;
+}
+
+int launch_threshold_edges(const float* K, int64_t n, float thr, int64_t* ei, float* ew, int64_t capacity,
+                           int64_t* out_count, uint32_t* scratch, size_t scratch_u32, hipStream_t s) {
+  return launch_threshold_edges_panel(K, n, 0, n, thr, ei, ei ? ei + capacity : nullptr, ew, capacity, out_count, scratch,
+                                      scratch_u32, s);
 }
 
 }  // namespace mmf

@@ -149,13 +149,22 @@ int launch_edge_cosine(const void* X, int64_t n, int64_t d, int dtype, const int
 int launch_sim_dense(const void* X, int64_t n, const void* Y, int64_t m, int64_t d, int dtype,
                      int metric, float lambda, const float* rx, const float* cy, float* out,
                      hipStream_t s);
+// rows [row0, row0 + rows) of the combined n x n similarity; out [rows, n]
 int launch_sim_dense_combined(const float* F, const float* P, int64_t n, int64_t d, int64_t dp,
-                              float lambda_h, float lambda_g, const float* nf, float* out,
+                              float lambda_h, float lambda_g, const float* nf, int64_t row0, int64_t rows, float* out,
                               hipStream_t s);
 
 // mmf_edges.hip
 int launch_offdiag_lower_median(const float* K, int64_t n, float* out, uint32_t* scratch /*>=1024 u32*/,
                                 hipStream_t s);
+// the radix select in pieces (matrices recomputed panel by panel): begin; for pass 0..3 { accumulate panels; next }
+size_t median_state_bytes();
+int launch_median_begin(void* state, int64_t n, hipStream_t s);
+int launch_median_accumulate(const float* K, int64_t n, int64_t row0, int64_t rows, void* state, int pass, hipStream_t s);
+int launch_median_next(void* state, int pass, float* out, hipStream_t s);
+int launch_threshold_edges_panel(const float* K, int64_t n, int64_t row0, int64_t rows, float thr, int64_t* ei_row,
+                                 int64_t* ei_col, float* ew, int64_t capacity, int64_t* out_count, uint32_t* scratch,
+                                 size_t scratch_u32, hipStream_t s);
 int launch_threshold_edges(const float* K, int64_t n, float thr, int64_t* ei, float* ew,
                            int64_t capacity, int64_t* out_count, uint32_t* scratch, size_t scratch_u32,
                            hipStream_t s);

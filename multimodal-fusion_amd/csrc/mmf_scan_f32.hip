@@ -48,6 +48,7 @@ struct ScanF32Args {
   // dense epilogue
   float* out;
   const float* P; int dp; float neg_lambda_g;
+  int64_t prow0;   // dense combined, panel form: query q of this launch is row prow0 + q of P
   int debug;   // MMF_F32_DEBUG (timing-only ablations): 1 skip epilogue, 2 skip staging
 };
 
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(F_NT, (MODE == MODE_DENSE || CAP <= 16) ? 2 : 1) vo
                 // K_g from the positions, canonical chains over dp (similarity_kernel.py:79-84, 122)
                 float ni = 0.f, nj = 0.f, dp_ = 0.f;
                 for (int e = 0; e < a.dp; ++e) {
-                  const float pi = a.P[q * a.dp + e], pj = a.P[j * a.dp + e];
+                  const float pi = a.P[(a.prow0 + q) * a.dp + e], pj = a.P[j * a.dp + e];
                   ni = __builtin_fmaf(pi, pi, ni);
                   nj = __builtin_fmaf(pj, pj, nj);
                   dp_ = __builtin_fmaf(pi, pj, dp_);
@@ -482,19 +483,19 @@ int launch_sim_dense(const void* X, int64_t n, const void* Y, int64_t m, int64_t
 }
 
 int launch_sim_dense_combined(const float* F, const float* P, int64_t n, int64_t d, int64_t dp, float lambda_h,
-                              float lambda_g, const float* nf, float* out, hipStream_t s) {
-  if (n <= 0) return MMF_OK;
+                              float lambda_g, const float* nf, int64_t row0, int64_t rows, float* out, hipStream_t s) {
+  if (n <= 0 || rows <= 0) return MMF_OK;
   ScanF32Args a{};
-  a.X = F; a.Y = F; a.n = n; a.m = n; a.d = d; a.dtype = MMF_F32;
-  a.rx = nf; a.cy = nf; a.row_ids = nullptr; a.n_rows = n;
+  a.X = F + row0 * d; a.Y = F; a.n = rows; a.m = n; a.d = d; a.dtype = MMF_F32;
+  a.rx = nf + row0; a.cy = nf; a.row_ids = nullptr; a.n_rows = rows;
   a.neg_lambda = -lambda_h; a.kk = 0;
   const int64_t total_tiles = (n + F_CT - 1) / F_CT;
-  const int64_t rbs = (n + F_QT - 1) / F_QT;
+  const int64_t rbs = (rows + F_QT - 1) / F_QT;
   int64_t splits = (1024 + rbs - 1) / rbs;
   if (splits > total_tiles) splits = total_tiles;
   a.col_splits = (int)splits;
   a.tiles_per_split = (total_tiles + splits - 1) / splits;
-  a.out = out; a.P = P; a.dp = (int)dp; a.neg_lambda_g = -lambda_g;
+  a.out = out; a.P = P; a.dp = (int)dp; a.neg_lambda_g = -lambda_g; a.prow0 = row0;
   a.metric = MMF_RBF;
   return launch_f32_t<MODE_DENSE, 16>(a, can_vec4(F, F, d, MMF_F32), rbs * splits, s);
 }

@@ -166,6 +166,44 @@ def threshold_edges(K: torch.Tensor, threshold: float) -> Tuple[torch.Tensor, to
     return ei, ew
 
 
+def combined_offdiag_median(F: torch.Tensor, P: torch.Tensor, lambda_h: float = 1.0, lambda_g: float = 1.0,
+                            panel_rows: int = 0) -> torch.Tensor:
+    """Lower median of the off-diagonal entries of K = K_h * K_g without materialising K (recomputed in row panels)."""
+    F = _feat(F, "combined_offdiag_median features").float()
+    P = _feat(P, "combined_offdiag_median positions").float()
+    _need_gpu(F, "combined_offdiag_median")
+    if P.device != F.device or P.shape[0] != F.shape[0]:
+        raise ValueError("combined_offdiag_median: features and positions must share device and N")
+    out = torch.empty((), dtype=torch.float32, device=F.device)
+    rc = _lib.lib().mmf_combined_offdiag_median(_p(F), _p(P), F.shape[0], F.shape[1], P.shape[1], float(lambda_h),
+                                                float(lambda_g), int(panel_rows), _p(out), F.device.index or 0,
+                                                _stream(F.device))
+    _lib.check(rc, "mmf_combined_offdiag_median")
+    return out
+
+
+def combined_threshold_edges(F: torch.Tensor, P: torch.Tensor, threshold: float, lambda_h: float = 1.0,
+                             lambda_g: float = 1.0, panel_rows: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """threshold_edges of K = K_h * K_g without materialising K: one sweep to count, one to fill."""
+    F = _feat(F, "combined_threshold_edges features").float()
+    P = _feat(P, "combined_threshold_edges positions").float()
+    _need_gpu(F, "combined_threshold_edges")
+    if P.device != F.device or P.shape[0] != F.shape[0]:
+        raise ValueError("combined_threshold_edges: features and positions must share device and N")
+    n, d = F.shape
+    cnt = torch.zeros((), dtype=torch.int64, device=F.device)
+    L = _lib.lib()
+    args = (_p(F), _p(P), n, d, P.shape[1], float(lambda_h), float(lambda_g), float(threshold), int(panel_rows))
+    dev, st = F.device.index or 0, _stream(F.device)
+    _lib.check(L.mmf_combined_threshold_edges(*args, None, None, 0, _p(cnt), dev, st), "mmf_combined_threshold_edges")
+    E = int(cnt.item())
+    ei = torch.empty((2, E), dtype=torch.int64, device=F.device)
+    ew = torch.empty((E,), dtype=torch.float32, device=F.device)
+    if E:
+        _lib.check(L.mmf_combined_threshold_edges(*args, _p(ei), _p(ew), E, _p(cnt), dev, st), "mmf_combined_threshold_edges")
+    return ei, ew
+
+
 # ---------------------------------------------------------------------------------------------------
 # phase API of the fast path (row-sharded multi-GPU driver, distributed.py)
 # ---------------------------------------------------------------------------------------------------
