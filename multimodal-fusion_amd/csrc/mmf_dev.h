@@ -331,39 +331,23 @@ struct LaneList {
   // id0 + (r&3) + 8*(r>>2) + 4*(lane>>5).  Called by the whole wave when any lane has a hit.
   template <bool EXACT>
   __device__ __forceinline__ void offer_tile(const f32x16& v, uint32_t id0, int half, int kk, float margin) {
-#pragma unroll 1
-    for (int r = 0; r < 16; ++r) {
+    // only the accumulator rows that hold a hit in some lane run the push code (16 branch-free compares find them;
+    // thr only rises meanwhile, so the mask is a superset)
+    uint32_t rmask = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rmask |= (__any(v[r] >= thr) ? 1u : 0u) << r;
+    while (rmask) {
+      const int r = __builtin_ctz(rmask);
+      rmask &= rmask - 1;
       const float x = v[r];
       bool hit = x >= thr;
-      if (__any(hit)) {
-        if (__any(hit && cnt >= CAP)) {
-          compact<EXACT>(kk, margin);
-          hit = x >= thr;
-        }
-        if (hit) {
-          if (cnt < CAP) push(x, id0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * half));
-          else overflow = 1;
-        }
+      if (__any(hit && cnt >= CAP)) {
+        compact<EXACT>(kk, margin);
+        hit = x >= thr;
       }
-    }
-  }
-
-  // Approximate mode, warm lists (every lane already has a real threshold): the common case of the
-  // 16-bit scan.  One compaction site ahead of the pushes guarantees two free slots per lane; the
-  // 16 registers are tested by straight-line code (no dynamic register index), and a hit that still
-  // finds its list full is dropped under the audited-loss rule (finish()), never blocks.
-  __device__ __forceinline__ void offer_tile_warm(const f32x16& v, uint32_t id0, int half, int kk, float margin) {
-    if (__any(cnt >= CAP - 1)) compact<false>(kk, margin);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float x = v[r];
-      if (x >= thr) {
-        if (cnt < CAP) {
-          push(x, id0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * half));
-        } else {
-          lost = fmaxf(lost, x);
-          thr = fmaxf(thr, lost);
-        }
+      if (hit) {
+        if (cnt < CAP) push(x, id0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * half));
+        else overflow = 1;
       }
     }
   }
