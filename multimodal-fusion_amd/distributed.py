@@ -78,6 +78,22 @@ def _allreduce_max(t: torch.Tensor, group) -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
 
 
+# Exchange buffers of the pipelined driver, kept between calls: allocating half a gigabyte per step costs most of a
+# millisecond of host time in the caching allocator, which at 8 GPUs is a tenth of the step.  A call ends with the
+# library's stream synchronisation, so the previous call's work on them is finished before the next one starts.
+_BUFFERS: dict = {}
+
+
+def _buffer(key, shape, dtype, device):
+    full_key = (key, tuple(shape), dtype, device)
+    buf = _BUFFERS.get(full_key)
+    if buf is None:
+        if len(_BUFFERS) > 64:
+            _BUFFERS.clear()
+        buf = _BUFFERS[full_key] = torch.empty(shape, dtype=dtype, device=device)
+    return buf
+
+
 def _pick_chunks(rows: int, world: int, chunks: Optional[int]) -> int:
     """Pieces the operand exchange is cut into (each piece: one all-gather + one scan launch)."""
     if chunks is not None:
@@ -106,27 +122,34 @@ def _overlapped_simtopk(x_local, n_total, lo, hi, world, *, metric, lam, k, excl
     rows_pad = (rows + 255) // 256 * 256
     z16 = torch.float16 if operand == "f16" else torch.bfloat16
     # ---- local phase -------------------------------------------------------------------------------------------
-    pack_l = torch.zeros((5, rows_pad), dtype=torch.float32, device=dev)          # scal, zn, rn, un, cb
+    pack_l = _buffer("pack", (5, rows_pad), torch.float32, dev)                    # scal, zn, rn, un, cb
+    if rows_pad != rows:
+        pack_l[:, rows:].zero_()
     maxn = torch.zeros((1,), dtype=torch.float32, device=dev)
     ops.row_scalars(x_local, metric, pack_l[0], maxn)
     if metric != "cosine":
         _allreduce_max(maxn, group)                      # the common power-of-two scale needs the global maximum
-    z_l = torch.empty((rows_pad, dp), dtype=z16, device=dev)
+    z_l = _buffer("z_l", (rows_pad, dp), z16, dev)
     if rows_pad != rows:
         z_l[rows:].zero_()
-    send = torch.empty((5 * rows + 4,), dtype=torch.float32, device=dev)         # per-row scalars + this shard's maxima
+    send = _buffer("send", (5 * rows + 4,), torch.float32, dev)                   # per-row scalars + this shard's maxima
     max4 = send[5 * rows:]
     max4.zero_()
     ops.prep_rows(x_local, metric, operand, pack_l[0], maxn, z_l, pack_l[1], pack_l[2], pack_l[3], pack_l[4], max4)
     send[:5 * rows].view(5, rows).copy_(pack_l[:, :rows])
     # ---- exchanges, in the order the scan needs them (collectives of a group complete in issue order) ------------
-    recv = torch.empty((world, 5 * rows + 4), dtype=torch.float32, device=dev)
+    recv = _buffer("recv", (world, 5 * rows + 4), torch.float32, dev)
     _gather_into(recv, send, group)
     m_c = world * seg
     m_pad = (m_c + 255) // 256 * 256
-    zc = torch.empty((S, m_pad + 256, dp), dtype=z16, device=dev)
-    zc[:, m_c:].zero_()
-    side_stream = torch.cuda.Stream(device=dev)
+    zc_key = ("zc", (S, m_pad + 256, dp), z16, dev)
+    fresh = zc_key not in _BUFFERS
+    zc = _buffer("zc", (S, m_pad + 256, dp), z16, dev)
+    if fresh:
+        zc[:, m_c:].zero_()                              # the padding rows stay zero: the gathers never touch them
+    side_stream = _BUFFERS.get(("side_stream", dev))
+    if side_stream is None:
+        side_stream = _BUFFERS[("side_stream", dev)] = torch.cuda.Stream(device=dev)
     events = []
 
     def arrival(work):
@@ -139,13 +162,17 @@ def _overlapped_simtopk(x_local, n_total, lo, hi, world, *, metric, lam, k, excl
         return ev
     for c in range(S):
         events.append(arrival(_gather_into(zc[c, :m_c], z_l[c * seg:(c + 1) * seg], group, async_op=True)))
-    full = torch.empty((n_total, d), dtype=x_local.dtype, device=dev)
+    full = _buffer("full", (n_total, d), x_local.dtype, dev)
     ev_full = arrival(_gather_into(full, x_local, group, async_op=True))
     # ---- candidate-side scalars out of the small gather (overlaps the chunk exchange) ----------------------------
     max_all = recv[:, 5 * rows:].max(dim=0).values.contiguous()
     per_row = recv[:, :5 * rows].view(world, 5, rows)
     c_scal = per_row[:, 0].reshape(n_total)
-    cb = torch.full((S, m_pad + 256), float("-inf"), dtype=torch.float32, device=dev)
+    cb_key = ("cb", (S, m_pad + 256), torch.float32, dev)
+    fresh_cb = cb_key not in _BUFFERS
+    cb = _buffer("cb", (S, m_pad + 256), torch.float32, dev)
+    if fresh_cb:
+        cb.fill_(float("-inf"))                          # the padding entries stay -inf
     cb[:, :m_c] = per_row[:, 4].reshape(world, S, seg).permute(1, 0, 2).reshape(S, m_c)
     panels = [dict(Z=zc[c], cb=cb[c], m=m_c, m_pad=m_pad, seg_len=seg, seg_stride=rows, id_base=c * seg, event=events[c])
               for c in range(S)]
