@@ -117,7 +117,8 @@ typedef struct mmf_simtopk_stats {
   int      precision_used; /* MMF_PREC_EXACT or MMF_PREC_FAST                                    */
   int      col_splits;     /* column ranges per row block actually used                         */
   int      scan_grid;      /* workgroups launched by the scan kernel                             */
-  int      reserved0;
+  float    scan_wait_ms;   /* paneled scan, profile = 1: part of scan_ms the stream spent waiting for panels'
+                              ready_events (exposed exchange time), 0 otherwise                   */
   int64_t  overflow_rows;  /* fallback rows whose candidate list overflowed (near-ties beyond capacity) */
   int64_t  short_rows;     /* fallback rows whose lists held fewer than k admissible candidates   */
 } mmf_simtopk_stats;
@@ -158,6 +159,9 @@ typedef struct mmf_prepared_side {
 } mmf_prepared_side;
 
 int64_t mmf_padded_dim(int64_t d);
+/* 1 when the 16-bit scan (MMF_PREC_FAST / the phase API) handles feature dim d with k neighbours
+ * (+ self when exclude_self), else 0 (such shapes run on the exact scan under MMF_PREC_AUTO). */
+int mmf_fast_scan_supported(int64_t d, int k, int exclude_self);
 int mmf_row_scalars(const void* X, int64_t n, int64_t d, int in_dtype, int metric, float* scal,
                     float* max_sq_norm, int device_id, void* hip_stream);
 int mmf_prep_rows(const void* X, int64_t n, int64_t d, int in_dtype, int metric, int operand,

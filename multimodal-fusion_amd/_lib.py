@@ -35,7 +35,7 @@ class SimtopkStats(ctypes.Structure):
     _fields_ = [("scan_ms", ctypes.c_float), ("prep_ms", ctypes.c_float), ("rerank_ms", ctypes.c_float),
                 ("fallback_ms", ctypes.c_float), ("candidates", ctypes.c_int64), ("fallback_rows", ctypes.c_int64),
                 ("precision_used", ctypes.c_int), ("col_splits", ctypes.c_int), ("scan_grid", ctypes.c_int),
-                ("reserved0", ctypes.c_int), ("overflow_rows", ctypes.c_int64), ("short_rows", ctypes.c_int64)]
+                ("scan_wait_ms", ctypes.c_float), ("overflow_rows", ctypes.c_int64), ("short_rows", ctypes.c_int64)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_ if not f.startswith("reserved")}
@@ -44,7 +44,7 @@ class SimtopkStats(ctypes.Structure):
 _lib = None
 
 EXPORTS = ["mmf_version", "mmf_last_error", "mmf_simtopk", "mmf_simtopk_ex", "mmf_row_scalars", "mmf_prep_rows",
-           "mmf_simtopk_prepared", "mmf_simtopk_panels", "mmf_padded_dim", "mmf_topk_merge", "mmf_edge_cosine",
+           "mmf_simtopk_prepared", "mmf_simtopk_panels", "mmf_padded_dim", "mmf_fast_scan_supported", "mmf_topk_merge", "mmf_edge_cosine",
            "mmf_sim_dense", "mmf_sim_dense_combined", "mmf_offdiag_lower_median", "mmf_threshold_edges", "mmf_combined_offdiag_median", "mmf_combined_threshold_edges",
            "mmf_release_workspaces"]
 
@@ -65,6 +65,7 @@ def lib() -> ctypes.CDLL:
     L.mmf_simtopk_ex.argtypes = [vp, i64, vp, i64, i64, ci, ci, f32, ci, ci, i64, i64, vp, vp,
                                  ctypes.POINTER(SimtopkOpts), ctypes.POINTER(SimtopkStats), ci, vp]
     L.mmf_padded_dim.argtypes = [i64]
+    L.mmf_fast_scan_supported.argtypes = [i64, ci, ci]
     L.mmf_row_scalars.argtypes = [vp, i64, i64, ci, ci, vp, vp, ci, vp]
     L.mmf_prep_rows.argtypes = [vp, i64, i64, ci, ci, ci, vp, vp, vp, i64, vp, vp, vp, vp, vp, ci, vp]
     L.mmf_simtopk_prepared.argtypes = [vp, i64, vp, i64, i64, ci, ci, f32, ci, ci, i64, i64,

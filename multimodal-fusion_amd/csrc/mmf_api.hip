@@ -82,14 +82,40 @@ static int check_common(const void* X, int64_t n, int64_t m, int64_t d, int in_d
   return MMF_OK;
 }
 
+// HIP events are kept between calls (per device): creating and destroying eight of them per step showed up next to
+// an 8 ms per-rank step.  An EventTimer borrows two from the pool and hands them back when it goes out of scope.
+struct EventPool {
+  std::mutex mu;
+  std::map<int, std::vector<hipEvent_t>> idle;
+  hipEvent_t get(int dev) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto& v = idle[dev];
+      if (!v.empty()) { hipEvent_t e = v.back(); v.pop_back(); return e; }
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
+  void put(int dev, hipEvent_t e) {
+    if (!e) return;
+    std::lock_guard<std::mutex> lk(mu);
+    idle[dev].push_back(e);
+  }
+};
+static EventPool g_events;
+
 struct EventTimer {
   hipEvent_t a = nullptr, b = nullptr;
   bool on = false;
+  int dev = 0;
   int start(bool enable, hipStream_t s) {
     on = enable;
     if (!on) return MMF_OK;
-    MMF_HIP(hipEventCreate(&a));
-    MMF_HIP(hipEventCreate(&b));
+    MMF_HIP(hipGetDevice(&dev));
+    a = g_events.get(dev);
+    b = g_events.get(dev);
+    if (!a || !b) { set_error("hipEventCreate failed"); return MMF_E_HIP; }
     MMF_HIP(hipEventRecord(a, s));
     return MMF_OK;
   }
@@ -104,8 +130,8 @@ struct EventTimer {
     return t;
   }
   ~EventTimer() {
-    if (a) (void)hipEventDestroy(a);
-    if (b) (void)hipEventDestroy(b);
+    g_events.put(dev, a);
+    g_events.put(dev, b);
   }
 };
 
@@ -231,6 +257,7 @@ struct FastTail {
     MMF_HIP(hipMemsetAsync(fail_count, 0, 16, s));
     MMF_HIP(hipMemsetAsync(cand_total, 0, 1024, s));
     EventTimer t_scan, t_sel, t_fb;
+    EventTimer t_panel[16];
     int grid = 0;
     MMF_HIP(hipMemsetAsync(seed, 0x80, (size_t)n_seed * 8, s));   // kSeedNone, thresholds and dropped keys
     MMF_HIP(hipMemsetAsync(L.spill_cnt, 0, (size_t)n * 4, s));
@@ -249,11 +276,13 @@ struct FastTail {
       for (int p = 0; p < fo.n_panels; ++p) {
         const mmf_panel& P = fo.panels[p];
         if (P.ready_event) MMF_HIP(hipStreamWaitEvent(s, static_cast<hipEvent_t>(P.ready_event), 0));
+        MMF_TRY(t_panel[p].start(profile, s));       // behind the wait: launch-only time of this panel
         pn.list_base = list_base;
         list_base += 2 * panel_splits[p];
         pn.seg_len = (uint32_t)P.seg_len; pn.seg_stride = (uint32_t)P.seg_stride; pn.id_off = (uint32_t)P.id_base;
         MMF_TRY(launch_scan_b16(fo.ZQ, P.Z, P.cb, fo.q_zn, fo.q_rn, fo.q_un, fo.max_c, n, P.m, P.m_pad, fo.dp, d, fo.f16,
                                 metric, kk, panel_splits[p], L, scan_scratch, pn, s, &grid));
+        MMF_TRY(t_panel[p].stop(s));
       }
     }
     MMF_TRY(launch_scan_b16_audit(pn, L.overflow, n, s));
@@ -333,6 +362,12 @@ struct FastTail {
       stats->scan_ms = t_scan.ms();
       stats->rerank_ms = t_sel.ms();
       stats->fallback_ms = t_fb.ms();
+      if (profile && fo.n_panels > 0) {     // what the scan stream spent waiting for panels to arrive
+        float launches = 0.f;
+        for (int p = 0; p < fo.n_panels; ++p) launches += t_panel[p].ms();
+        const float w = stats->scan_ms - launches;
+        stats->scan_wait_ms = w > 0.f ? w : 0.f;
+      }
       stats->fallback_rows = h_fail;
       stats->overflow_rows = h_fail4[1];
       stats->short_rows = h_fail4[2];
@@ -552,6 +587,11 @@ int mmf_simtopk(const void* X, int64_t n, const void* Y, int64_t m, int64_t d, i
 }
 
 int64_t mmf_padded_dim(int64_t d) { return (int64_t)scan_bf16_dp(d); }
+
+int mmf_fast_scan_supported(int64_t d, int k, int exclude_self) {
+  if (d < 1 || k < 1) return 0;
+  return scan_bf16_supported(d, k + (exclude_self ? 1 : 0), MMF_F32);
+}
 
 int mmf_row_scalars(const void* X, int64_t n, int64_t d, int in_dtype, int metric, float* scal, float* max_sq_norm,
                     int device_id, void* hip_stream) {

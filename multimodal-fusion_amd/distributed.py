@@ -53,24 +53,57 @@ def all_gather_rows(x_local: torch.Tensor, n_total: int, group=None) -> torch.Te
     return full
 
 
-def _gather_into(out: torch.Tensor, inp: torch.Tensor, group, async_op: bool = False):
-    """all_gather_into_tensor on flat views (rank-major concatenation; backends differ in which shaped
-    outputs they accept), with host staging under gloo (rehearsal only)."""
+def _staged(t: torch.Tensor, group) -> bool:
+    """gloo has no device collectives: the rehearsal path stages device tensors through the host.  The
+    production backend is "nccl" (= RCCL over xGMI on ROCm) and never stages."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _gather_into(out: torch.Tensor, inp: torch.Tensor, group) -> None:
+    """Blocking all_gather_into_tensor on flat views (rank-major concatenation; backends differ in which
+    shaped outputs they accept)."""
     if not out.is_contiguous():
         raise ValueError("all-gather output must be contiguous")
     flat_in = inp.contiguous().view(-1)
     if flat_in.numel() * dist.get_world_size(group) != out.numel():
         raise ValueError("all-gather output must hold world_size inputs")
-    if inp.is_cuda and dist.get_backend(group) == "gloo":
+    if _staged(inp, group):
         o = torch.empty((out.numel(),), dtype=out.dtype)
         dist.all_gather_into_tensor(o, flat_in.cpu(), group=group)
         out.view(-1).copy_(o)
-        return None
-    return dist.all_gather_into_tensor(out.view(-1), flat_in, group=group, async_op=async_op)
+        return
+    dist.all_gather_into_tensor(out.view(-1), flat_in, group=group)
+
+
+def _gather_event(out: torch.Tensor, inp: torch.Tensor, group, side_stream) -> "torch.cuda.Event":
+    """Issue one all-gather of the pipelined exchange and return the event that fires when `out` is complete.
+    nccl: the collective is asynchronous (it runs on the backend's stream behind the work the current stream has
+    queued so far); the side stream waits for it and records the event, the current stream is never blocked.
+    gloo rehearsal: the gather itself is a blocking host collective; its result is copied to the device ON THE SIDE
+    STREAM and the event recorded behind the copy, so consumers go through the same event hand-off
+    (mmf_panel.ready_event / select_wait_event) as with nccl."""
+    if not out.is_contiguous():
+        raise ValueError("all-gather output must be contiguous")
+    flat_in = inp.contiguous().view(-1)
+    if flat_in.numel() * dist.get_world_size(group) != out.numel():
+        raise ValueError("all-gather output must hold world_size inputs")
+    ev = torch.cuda.Event()
+    if _staged(inp, group):
+        host = torch.empty((out.numel(),), dtype=out.dtype)
+        dist.all_gather_into_tensor(host, flat_in.cpu(), group=group)       # .cpu() waits for the producer stream
+        with torch.cuda.stream(side_stream):
+            out.view(-1).copy_(host)
+            ev.record(side_stream)
+        return ev
+    work = dist.all_gather_into_tensor(out.view(-1), flat_in, group=group, async_op=True)
+    with torch.cuda.stream(side_stream):
+        work.wait()
+        ev.record(side_stream)
+    return ev
 
 
 def _allreduce_max(t: torch.Tensor, group) -> None:
-    if t.is_cuda and dist.get_backend(group) == "gloo":
+    if _staged(t, group):
         c = t.cpu()
         dist.all_reduce(c, op=dist.ReduceOp.MAX, group=group)
         t.copy_(c)
@@ -81,6 +114,9 @@ def _allreduce_max(t: torch.Tensor, group) -> None:
 # Exchange buffers of the pipelined driver, kept between calls: allocating half a gigabyte per step costs most of a
 # millisecond of host time in the caching allocator, which at 8 GPUs is a tenth of the step.  A call ends with the
 # library's stream synchronisation, so the previous call's work on them is finished before the next one starts.
+# The buffers are keyed by their padded shapes only, so everything the gathers do not overwrite (padding rows and
+# padding biases) is re-established on EVERY call: a smaller problem that lands in the same padded shape must not
+# see the previous call's operands behind its own.
 _BUFFERS: dict = {}
 
 
@@ -142,37 +178,20 @@ def _overlapped_simtopk(x_local, n_total, lo, hi, world, *, metric, lam, k, excl
     _gather_into(recv, send, group)
     m_c = world * seg
     m_pad = (m_c + 255) // 256 * 256
-    zc_key = ("zc", (S, m_pad + 256, dp), z16, dev)
-    fresh = zc_key not in _BUFFERS
     zc = _buffer("zc", (S, m_pad + 256, dp), z16, dev)
-    if fresh:
-        zc[:, m_c:].zero_()                              # the padding rows stay zero: the gathers never touch them
+    zc[:, m_c:].zero_()                                  # padding rows (never touched by the gathers): zero operands ...
+    cb = _buffer("cb", (S, m_pad + 256), torch.float32, dev)
+    cb[:, m_c:].fill_(float("-inf"))                     # ... and -inf biases, the scan's only column mask
     side_stream = _BUFFERS.get(("side_stream", dev))
     if side_stream is None:
         side_stream = _BUFFERS[("side_stream", dev)] = torch.cuda.Stream(device=dev)
-    events = []
-
-    def arrival(work):
-        if work is None:
-            return None
-        ev = torch.cuda.Event()
-        with torch.cuda.stream(side_stream):
-            work.wait()
-            ev.record(side_stream)
-        return ev
-    for c in range(S):
-        events.append(arrival(_gather_into(zc[c, :m_c], z_l[c * seg:(c + 1) * seg], group, async_op=True)))
+    events = [_gather_event(zc[c, :m_c], z_l[c * seg:(c + 1) * seg], group, side_stream) for c in range(S)]
     full = _buffer("full", (n_total, d), x_local.dtype, dev)
-    ev_full = arrival(_gather_into(full, x_local, group, async_op=True))
+    ev_full = _gather_event(full, x_local, group, side_stream)
     # ---- candidate-side scalars out of the small gather (overlaps the chunk exchange) ----------------------------
     max_all = recv[:, 5 * rows:].max(dim=0).values.contiguous()
     per_row = recv[:, :5 * rows].view(world, 5, rows)
     c_scal = per_row[:, 0].reshape(n_total)
-    cb_key = ("cb", (S, m_pad + 256), torch.float32, dev)
-    fresh_cb = cb_key not in _BUFFERS
-    cb = _buffer("cb", (S, m_pad + 256), torch.float32, dev)
-    if fresh_cb:
-        cb.fill_(float("-inf"))                          # the padding entries stay -inf
     cb[:, :m_c] = per_row[:, 4].reshape(world, S, seg).permute(1, 0, 2).reshape(S, m_c)
     panels = [dict(Z=zc[c], cb=cb[c], m=m_c, m_pad=m_pad, seg_len=seg, seg_stride=rows, id_base=c * seg, event=events[c])
               for c in range(S)]
@@ -180,6 +199,20 @@ def _overlapped_simtopk(x_local, n_total, lo, hi, world, *, metric, lam, k, excl
     return ops.simtopk_panels(x_local, full, q, c_scal, panels, max_all, operand=operand, metric=metric, lam=lam, k=k,
                               exclude_self=exclude_self, row_offset=lo, col_offset=0, wait_event=ev_full,
                               col_splits=col_splits, profile=return_stats, return_stats=return_stats)
+
+
+def pick_driver(x_local: torch.Tensor, n_total: int, world: int, *, metric="cosine", k: int = 5, exclude_self: bool = True,
+                precision: str = "auto", overlap: Optional[bool] = None, op: Optional[Callable] = None) -> str:
+    """Which of the two drivers sharded_simtopk runs for these arguments: "pipelined" or "simple".  Pure shape /
+    argument logic (no collective, no device work), so every rank reaches the same answer on its own."""
+    if op is not None or world <= 1 or overlap is False or not x_local.is_cuda or not isinstance(metric, str):
+        return "simple"
+    from . import ops as _ops
+    if (n_total % world) == 0 and precision in ("auto", "fast", "fast_bf16") \
+            and _ops.fast_scan_supported(x_local.shape[1], k, exclude_self) \
+            and x_local.dtype in (torch.float32, torch.float16, torch.bfloat16):
+        return "pipelined"
+    return "simple"
 
 
 def sharded_simtopk(x_local: torch.Tensor, n_total: int, *, metric="cosine", lam: float = 1.0, k: int = 5,
@@ -198,20 +231,20 @@ def sharded_simtopk(x_local: torch.Tensor, n_total: int, *, metric="cosine", lam
     lo, hi = shard_bounds(n_total, world, rank)
     if x_local.shape[0] != hi - lo:
         raise ValueError(f"rank {rank}: shard has {x_local.shape[0]} rows, expected {hi - lo}")
-    if op is None and world > 1 and overlap is not False and x_local.is_cuda and isinstance(metric, str):
-        from . import ops as _ops
-        kk = k + (1 if exclude_self else 0)
-        equal = (n_total % world) == 0
-        if equal and precision in ("auto", "fast", "fast_bf16") and _ops.padded_dim(x_local.shape[1]) > 0 and kk <= 20 \
-                and x_local.dtype in (torch.float32, torch.float16, torch.bfloat16):
-            out = _overlapped_simtopk(x_local.contiguous(), n_total, lo, hi, world, metric=metric, lam=lam, k=k,
-                                      exclude_self=exclude_self, operand="bf16" if precision == "fast_bf16" else "f16",
-                                      group=group, return_stats=return_stats, chunks=chunks, col_splits=col_splits)
-            idx, val = out[0], out[1]
-            if gather_output:
-                idx = all_gather_rows(idx, n_total, group)
-                val = all_gather_rows(val, n_total, group)
-            return (idx, val, out[2]) if return_stats else (idx, val)
+    driver = pick_driver(x_local, n_total, world, metric=metric, k=k, exclude_self=exclude_self, precision=precision,
+                         overlap=overlap, op=op)
+    if driver == "pipelined":
+        out = _overlapped_simtopk(x_local.contiguous(), n_total, lo, hi, world, metric=metric, lam=lam, k=k,
+                                  exclude_self=exclude_self, operand="bf16" if precision == "fast_bf16" else "f16",
+                                  group=group, return_stats=return_stats, chunks=chunks, col_splits=col_splits)
+        idx, val = out[0], out[1]
+        if gather_output:
+            idx = all_gather_rows(idx, n_total, group)
+            val = all_gather_rows(val, n_total, group)
+        if return_stats:
+            out[2]["driver"] = "pipelined"
+            return idx, val, out[2]
+        return idx, val
     full = all_gather_rows(x_local, n_total, group) if world > 1 else x_local
     if op is None:
         from . import ops
@@ -233,5 +266,7 @@ def sharded_simtopk(x_local: torch.Tensor, n_total: int, *, metric="cosine", lam
         idx = all_gather_rows(idx, n_total, group)
         val = all_gather_rows(val, n_total, group)
     if return_stats:
+        if stats is not None:
+            stats["driver"] = "simple"
         return idx, val, stats
     return idx, val

@@ -215,6 +215,11 @@ def padded_dim(d: int) -> int:
     return int(_lib.lib().mmf_padded_dim(int(d)))
 
 
+def fast_scan_supported(d: int, k: int, exclude_self: bool = True) -> bool:
+    """Whether the 16-bit scan (and with it the phase API) handles this feature dim and k."""
+    return bool(_lib.lib().mmf_fast_scan_supported(int(d), int(k), int(bool(exclude_self))))
+
+
 def row_scalars(X: torch.Tensor, metric, scal: torch.Tensor, max_sq_norm: Optional[torch.Tensor] = None) -> None:
     """scal[i] = canonical n_i (clamped norm for cosine); max_sq_norm[0] is raised to max n_i."""
     X = _feat(X, "row_scalars X")

@@ -1,26 +1,91 @@
-"""Multi-rank rehearsal on ONE GPU (gloo + host staging): every rank runs the overlapped phase path and
-the simple path and checks both against the unsharded result.  Launch with torch.distributed.run."""
-import os, sys, torch, torch.distributed as dist
-sys.path.insert(0, '.')
-from importlib import import_module
-import multimodal_fusion_amd as mmf
+"""Multi-rank rehearsal on ONE GPU (gloo + host staging): every rank runs the pipelined driver and the simple driver
+of multimodal-fusion_amd/distributed.py and checks both against the unsharded result, bit for bit.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node {2,4} --master-addr 127.0.0.1 --master-port P \
+        scripts/rehearse_shards.py
+
+Covers: all four metrics; f32 / f16 / bf16 rows; f16 and bf16 scan operands; gather_output; forced chunk counts and
+column splits; REPEATED calls that land in the same padded exchange buffers with fewer rows, other data and another d
+(the buffers are cached between calls, so whatever the gathers do not overwrite must be re-established every time);
+and the event hand-off (panel ready_events and select_wait_event are recorded on the side stream under gloo as well).
+tests/test_gpu_distributed.py runs this under pytest -m gpu."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from importlib import import_module   # noqa: E402
+
+import multimodal_fusion_amd as mmf   # noqa: E402
+from bench import make_rows            # noqa: E402
+
 dmod = import_module("multimodal_fusion_amd.distributed")
-from bench import make_rows
 torch.cuda.set_device(0)
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 dev = torch.device("cuda", 0)
-for N, d, metric, dt in ((16384, 512, "cosine", torch.float32), (8192, 128, "neg_sq_l2", torch.float32),
-                         (8192, 256, "cosine", torch.float16), (8192, 1024, "dot", torch.bfloat16)):
-    X = (make_rows(0, N, d, dev) * (1.0 if metric == "cosine" else 2.5)).to(dt)
-    ref_i, ref_v = mmf.simtopk(X, metric=metric, k=5)
+
+
+def rows(n, d, seed, scale, dt):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x = torch.randn((n, d), generator=g, device=dev)
+    x = x / x.norm(dim=1, keepdim=True) * scale
+    return x.to(dt)
+
+
+def check(X, N, what, **kw):
+    metric = kw.get("metric", "cosine")
+    ref_kw = {k: v for k, v in kw.items() if k in ("metric", "lam", "k", "precision")}
+    ref_i, ref_v = mmf.simtopk(X, **ref_kw)
     lo, hi = dmod.shard_bounds(N, world, rank)
+    i, v, st = dmod.sharded_simtopk(X[lo:hi].clone(), N, return_stats=True, **kw)
+    same_v = torch.allclose(v, ref_v[lo:hi], rtol=0, atol=1e-5) if metric == "rbf" else torch.equal(v, ref_v[lo:hi])
+    ok = torch.equal(i, ref_i[lo:hi]) and same_v
+    print(f"rank {rank}/{world} {what}: driver={st['driver']} wait={st.get('scan_wait_ms', 0.0):.3f} ms "
+          f"{'OK' if ok else 'MISMATCH'}", flush=True)
+    assert ok, what
+    return st["driver"], ref_i, ref_v
+
+
+cases = ((16384, 512, "cosine", 1.0, torch.float32), (8192, 128, "neg_sq_l2", 2.5, torch.float32),
+         (8192, 256, "cosine", 1.0, torch.float16), (8192, 1024, "dot", 2.5, torch.bfloat16),
+         (8192, 200, "rbf", 0.6, torch.float32))
+for N, d, metric, scale, dt in cases:
+    X = (make_rows(0, N, d, dev) * scale).to(dt)
     for overlap in (True, False):
-        i, v = dmod.sharded_simtopk(X[lo:hi].clone(), N, metric=metric, k=5, overlap=overlap)
-        ok = torch.equal(i, ref_i[lo:hi]) and torch.equal(v, ref_v[lo:hi])
-        print(f"rank {rank}/{world} N={N} {metric} overlap={overlap}: {'OK' if ok else 'MISMATCH'}", flush=True)
-        assert ok
-    gi, gv = dmod.sharded_simtopk(X[lo:hi].clone(), N, metric=metric, k=5, gather_output=True)
-    assert torch.equal(gi, ref_i) and torch.equal(gv, ref_v)
+        drv, ref_i, ref_v = check(X, N, f"N={N} d={d} {metric} {str(dt)[6:]} overlap={overlap}", metric=metric, lam=0.5, k=5,
+                                  overlap=overlap)
+        assert drv == ("pipelined" if overlap else "simple")
+    lo, hi = dmod.shard_bounds(N, world, rank)
+    gi, gv = dmod.sharded_simtopk(X[lo:hi].clone(), N, metric=metric, lam=0.5, k=5, gather_output=True)
+    assert torch.equal(gi, ref_i) and (torch.allclose(gv, ref_v, rtol=0, atol=1e-5) if metric == "rbf" else torch.equal(gv, ref_v))
+
+# bf16 scan operands, forced chunking / column splits, larger k
+X = make_rows(0, 16384, 512, dev)
+check(X, 16384, "fast_bf16 chunks=2", metric="cosine", k=5, precision="fast_bf16", chunks=2)
+check(X, 16384, "chunks=4 col_splits=4 k=16", metric="neg_sq_l2", k=16, chunks=4, col_splits=4)
+check(X, 16384, "chunks=1", metric="dot", k=3, chunks=1)
+
+# Repeated calls into the SAME cached exchange buffers (shape key = padded sizes): a larger problem first, then fewer
+# rows with other data (same 256-row bucket: m_c 8192 -> 8184 per chunk at chunks=2), then the same N at another d
+# that pads to the same operand width.  Each must equal its own unsharded result.
+for N, d, seed in ((16384, 512, 11), (16368, 512, 12), (16368, 500, 13), (16384, 512, 14), (16352, 384, 15)):
+    X = rows(N, d, seed, 1.0, torch.float32)
+    for metric in ("cosine", "neg_sq_l2"):
+        check(X, N, f"repeat N={N} d={d} {metric}", metric=metric, k=5, chunks=2)
+
+# uneven shards / exact precision take the simple driver
+X = make_rows(0, 8190 + world - 1, 128, dev)
+N = X.shape[0]
+if N % world:
+    drv, _, _ = check(X, N, f"uneven N={N}", metric="cosine", k=5)
+    assert drv == "simple"
+drv, _, _ = check(make_rows(0, 8192, 128, dev), 8192, "exact precision", metric="cosine", k=5, precision="exact")
+assert drv == "simple"
 dist.barrier()
+if rank == 0:
+    print("REHEARSAL OK", flush=True)
 dist.destroy_process_group()

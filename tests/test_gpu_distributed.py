@@ -1,0 +1,62 @@
+"""The multi-GPU drivers of multimodal-fusion_amd/distributed.py under pytest: fresh `torch.distributed.run` child
+processes, 2 and 4 ranks sharing this box's one GPU through gloo with host staging (scripts/rehearse_shards.py).
+
+What this covers that tests/test_distributed_cpu.py cannot (it substitutes the oracle for the device op and therefore
+only walks the simple driver): the pipelined driver end to end — sharded preparation, chunked operand exchange into
+cached buffers, per-panel arrival events recorded on the side stream, paneled scan with shared thresholds, f32 rows
+waited for only in front of the re-rank — for all four metrics, f32 / f16 / bf16 rows, f16 / bf16 operands,
+gather_output, and repeated calls that reuse the cached buffers with fewer rows / other d.
+What it cannot cover: RCCL itself (async all-gathers on the backend's stream) needs more than one GPU.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun(nproc, script_args, timeout=900):
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + script_args
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_rehearsal_both_drivers_equal_unsharded(world):
+    out = _torchrun(world, [os.path.join(ROOT, "scripts", "rehearse_shards.py")])
+    tail = (out.stdout[-3000:] + "\n---- stderr ----\n" + out.stderr[-3000:])
+    assert out.returncode == 0, tail
+    assert "REHEARSAL OK" in out.stdout and "MISMATCH" not in out.stdout, tail
+    assert "driver=pipelined" in out.stdout and "driver=simple" in out.stdout
+
+
+def test_bench_two_ranks_is_self_checking():
+    """bench.py --gpus 2 through gloo: one JSON line that names the driver, carries per-rank timing spread and
+    the result of its own bit-for-bit re-check of 256 rows per rank against the single-call path."""
+    out = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rows", "32768",
+                        "--steps", "2", "--warmup", "1"])
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    c = d["config"]
+    assert c["driver"] == "pipelined" and c["self_check"]["rows_per_rank"] == 256 and c["self_check"]["ok"] is True
+    pr = d["per_rank"]
+    for key in ("step_ms", "prep_ms", "scan_ms", "exposed_comm_ms", "rerank_ms", "fallback_ms"):
+        assert len(pr[key]) == 2 and pr[key][0] <= pr[key][1], key
+    assert abs(d["value"] - 32768.0 * 32768.0 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
