@@ -18,6 +18,14 @@ How the reference code is executed (no reference source is copied into this repo
 
 Only arrays (inputs + the reference's outputs) are written.  Versions used are recorded in
 meta.json next to the fixtures.
+
+    --only g8,signatures     regenerate just those pieces (the others are left as committed)
+
+G8 is the arithmetic of the two PIPELINES (process_single_file :566-585 and rebuild_hypergraph_from_similarity
+:818-897) obtained by calling the reference's own four arithmetic functions in the order and with the arguments those
+pipelines use; the HDF5 reads / writes around them cannot run here (h5py is not in the image) and are not faked.
+signatures.json additionally records the signatures of the seven HDF5 / pipeline functions: their `def` statements
+are compiled from the reference file's AST (annotations only need typing names), never called.
 """
 from __future__ import annotations
 
@@ -66,6 +74,16 @@ def positions(n, dp, seed):
 
 
 def main() -> None:
+    only = None
+    if "--only" in sys.argv:
+        only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
+
+    def want(tag):
+        return only is None or tag in only
+
+    def save(name, **arrays):
+        if want(name.split("_")[0]):
+            np.savez_compressed(os.path.join(OUT, name), **arrays)
     torch.set_num_threads(8)
     sk = load_module(os.path.join(REF, "build_hypergraph", "similarity_kernel.py"), "ref_sk_primary")
     sk2 = load_module(os.path.join(REF, "hypergraph", "build_hypergraph", "similarity_kernel.py"), "ref_sk_second")
@@ -99,7 +117,7 @@ def main() -> None:
         g1[f"N{N}_D{D}_Kzero"] = sk.compute_combined_similarity(X, Z, 1.0, 1.0).numpy()
         # the second copy of the file must agree bit for bit
         assert torch.equal(sk2.compute_morphological_similarity(X, 1.0), sk.compute_morphological_similarity(X, 1.0))
-    np.savez_compressed(os.path.join(OUT, "g1_dense.npz"), **g1)
+    save("g1_dense.npz", **g1)
 
     # ---- G2: a4 / a6 threshold edge builder -----------------------------------------------------
     g2 = {}
@@ -132,7 +150,7 @@ def main() -> None:
     except Exception as e:  # noqa: BLE001
         errs["n1"] = type(e).__name__
     g2["errors_json"] = np.array(json.dumps(errs))
-    np.savez_compressed(os.path.join(OUT, "g2_threshold.npz"), **g2)
+    save("g2_threshold.npz", **g2)
 
     # ---- G3: a7 cross-modal dense ---------------------------------------------------------------
     g3 = {}
@@ -147,7 +165,7 @@ def main() -> None:
         g3[f"N{N}_M{M}_S_lam0.5"] = S2.numpy()
         g3[f"N{N}_M{M}_stats_lam1"] = np.array([st[k] for k in ("mean", "std", "min", "max", "median")], dtype=np.float64)
         g3[f"N{N}_M{M}_stats_lam0.5"] = np.array([st2[k] for k in ("mean", "std", "min", "max", "median")], dtype=np.float64)
-    np.savez_compressed(os.path.join(OUT, "g3_cross.npz"), **g3)
+    save("g3_cross.npz", **g3)
 
     # ---- G4: a8 sklearn kNN on tie-free data ----------------------------------------------------
     g4 = {}
@@ -160,7 +178,7 @@ def main() -> None:
             dist, ind = knn.kneighbors(X.numpy())
             g4[f"N{N}_D{D}_k{k}_ind"] = ind.astype(np.int64)
             g4[f"N{N}_D{D}_k{k}_dist"] = dist.astype(np.float64)
-    np.savez_compressed(os.path.join(OUT, "g4_knn.npz"), **g4)
+    save("g4_knn.npz", **g4)
 
     # ---- G5: a8+a9+a10 whole build_hypergraph_knn_kmeans ----------------------------------------
     g5 = {}
@@ -184,7 +202,7 @@ def main() -> None:
         g5[f"{tag}_ei_sorted"] = e[:, order]
         g5[f"{tag}_ew_sorted"] = ew.numpy()[order]
         g5[f"{tag}_num_edges"] = np.array(st["num_edges"])
-    np.savez_compressed(os.path.join(OUT, "g5_knn_kmeans.npz"), **g5)
+    save("g5_knn_kmeans.npz", **g5)
 
     # ---- G6: tie cases --------------------------------------------------------------------------
     g6 = {}
@@ -198,14 +216,59 @@ def main() -> None:
         g6[f"{tag}_X"] = X.numpy()
         g6[f"{tag}_ind"] = ind.astype(np.int64)
         g6[f"{tag}_dist"] = dist.astype(np.float64)
-    np.savez_compressed(os.path.join(OUT, "g6_ties.npz"), **g6)
+    save("g6_ties.npz", **g6)
 
     # ---- G7: a5 both signatures -----------------------------------------------------------------
     X = unit_rows(50, 24, 9)
     P = positions(50, 2, 10)
-    np.savez_compressed(os.path.join(OUT, "g7_pool.npz"), X=X.numpy(), P=P.numpy(),
+    save("g7_pool.npz", X=X.numpy(), P=P.numpy(),
                         pool1=sk.mean_pool_with_similarity(X).numpy(),
                         pool2=sk2.mean_pool_with_similarity(X, P, 1.0, 1.0).numpy())
+
+    # ---- G8: the two pipelines' arithmetic, composed from the reference's own functions -----------
+    g8 = {}
+    Nw, Nt, D, S, G, k, H = 600, 48, 64, 40, 6, 5, 8
+    gen = torch.Generator().manual_seed(2024)
+    cent = torch.randn(60, D, generator=gen)
+    Wf = cent[torch.randint(0, 60, (Nw,), generator=gen)] * 0.4 + 0.05 * torch.randn(Nw, D, generator=gen)   # clustered patches
+    Wp = torch.rand(Nw, 2, generator=gen)
+    Tf = cent[torch.randint(0, 60, (Nt,), generator=gen)] * 0.4 + 0.05 * torch.randn(Nt, D, generator=gen)
+    lam_h, lam_g = 0.5, 2.0
+    # process_single_file, preprocess_hypergraph.py:566-585
+    sf, sp, wst, Kw = pp["aggregate_wsi_super_patches"](Wf, Wp, S, lam_h, lam_g, torch.device("cpu"))
+    sim, sst = pp["compute_wsi_tma_similarity"](sf, sp, Tf, lam_h, lam_g, torch.device("cpu"))
+    gl, gst = pp["group_by_similarity"](sim, G, method="kmeans")
+    ei, ew, hst = pp["build_hypergraph_knn_kmeans"](sf, Tf, gl, k, H, torch.device("cpu"))
+    e = ei.numpy()
+    order = np.lexsort((e[1], e[0]))
+    g8.update(wsi_features=Wf.numpy(), wsi_positions=Wp.numpy(), tma_features=Tf.numpy(),
+              params=np.array([S, G, k, H]), lambdas=np.array([lam_h, lam_g]),
+              super_features=sf.numpy(), super_positions=sp.numpy(), K_wsi=Kw.numpy(), sim=sim.numpy(),
+              group_labels=np.asarray(gl).astype(np.int64), ei_sorted=e[:, order], ew_sorted=ew.numpy()[order],
+              wsi_stats=np.array([wst["avg_intra_cluster_similarity"]] + [wst["wsi_similarity_matrix_stats"][q] for q in ("mean", "std", "min", "max", "median")], dtype=np.float64),
+              sim_stats=np.array([sst[q] for q in ("mean", "std", "min", "max", "median")], dtype=np.float64),
+              group_sizes=np.array(gst["group_sizes"], dtype=np.int64), num_edges=np.array(hst["num_edges"]))
+    # rebuild_hypergraph_from_similarity with num_wsi_super_patches = S2, num_groups = G2 (:818-867: lambdas are the
+    # literal 1.0s of the source, the stored K_wsi is handed to the aggregation), then the edge-weight median
+    # filter of :885-897 (three torch lines restated here on the reference's own edge weights)
+    S2, G2, ratio = 25, 4, 1.0
+    sf2, sp2, wst2, _ = pp["aggregate_wsi_super_patches"](Wf, Wp, S2, lambda_h=1.0, lambda_g=1.0, device=torch.device("cpu"),
+                                                          wsi_similarity_matrix=Kw)
+    sim2, sst2 = pp["compute_wsi_tma_similarity"](sf2, sp2, Tf, lambda_h=1.0, lambda_g=1.0, device=torch.device("cpu"))
+    gl2, gst2 = pp["group_by_similarity"](sim2, G2, method="kmeans")
+    ei2, ew2, hst2 = pp["build_hypergraph_knn_kmeans"](sf2, Tf, gl2, k, H, torch.device("cpu"))
+    med = ew2.median().item()
+    thr = med * ratio
+    mask = ew2 >= thr
+    e2 = ei2[:, mask].numpy()
+    w2 = ew2[mask].numpy()
+    order2 = np.lexsort((e2[1], e2[0]))
+    g8.update(rb_params=np.array([S2, G2]), rb_ratio=np.array(ratio), rb_super_features=sf2.numpy(), rb_super_positions=sp2.numpy(),
+              rb_sim=sim2.numpy(), rb_group_labels=np.asarray(gl2).astype(np.int64), rb_num_edges=np.array(hst2["num_edges"]),
+              rb_median=np.array(med, dtype=np.float64), rb_threshold=np.array(thr, dtype=np.float64),
+              rb_ei_sorted=e2[:, order2], rb_ew_sorted=w2[order2],
+              rb_sim_stats=np.array([sst2[q] for q in ("mean", "std", "min", "max", "median")], dtype=np.float64))
+    save("g8_pipeline.npz", **g8)
 
     # ---- signatures of the boundary functions (names, order, defaults): data, not code ----------
     import inspect
@@ -220,14 +283,25 @@ def main() -> None:
                                              "compute_combined_similarity", "build_weighted_hypergraph",
                                              "mean_pool_with_similarity", "build_hypergraph_data")}}
     sigs["build_hypergraph"].update({n: sig(pp[n]) for n in pp})
-    with open(os.path.join(OUT, "signatures.json"), "w") as fh:
-        json.dump(sigs, fh, indent=1, sort_keys=True)
+    # the HDF5 / pipeline functions: `def` statements only (never called — h5py is absent)
+    io_names = ["load_wsi_data", "load_tma_data", "save_hypergraph_to_h5", "process_single_file", "process_dataset",
+                "load_similarity_matrices", "rebuild_hypergraph_from_similarity", "batch_rebuild_hypergraph"]
+    io = load_functions(os.path.join(REF, "build_hypergraph", "preprocess_hypergraph.py"), io_names, dict(ns))
+    sigs["build_hypergraph"].update({n: sig(io[n]) for n in io_names})
+    ref_init = ast.parse(open(os.path.join(REF, "build_hypergraph", "__init__.py"), encoding="utf-8").read())
+    ref_all = [ast.literal_eval(n.value) for n in ref_init.body
+               if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") == "__all__"][0]
+    sigs["build_hypergraph.__all__"] = list(ref_all)
+    if want("signatures"):
+        with open(os.path.join(OUT, "signatures.json"), "w") as fh:
+            json.dump(sigs, fh, indent=1, sort_keys=True)
 
     meta = {"generator": "tests/golden/make_golden.py", "reference": "zz9tf/multimodal-fusion @ 2026-01-30",
             "torch": torch.__version__, "numpy": np.__version__, "sklearn": sklearn.__version__,
             "python": sys.version.split()[0], "torch_threads": torch.get_num_threads()}
-    with open(os.path.join(OUT, "meta.json"), "w") as fh:
-        json.dump(meta, fh, indent=1)
+    if only is None:
+        with open(os.path.join(OUT, "meta.json"), "w") as fh:
+            json.dump(meta, fh, indent=1)
     print("wrote fixtures to", OUT, meta)
 
 

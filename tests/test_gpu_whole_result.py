@@ -1,0 +1,113 @@
+"""Whole-result parity where the numbers are quoted.
+
+The 16-bit scan is exact only through its margin proof: every column that can be in the canonical
+top-k must survive the approximate filter.  Here the result of the fast path (f16 and bf16 operands) is compared with
+the exact f32 scan over EVERY row — indices and scores, torch.equal — at the BASELINE configurations' full sizes,
+and both with the CPU oracle on rows spread over the whole matrix.  The exact scan forms canonical keys straight out
+of v_mfma_f32_32x32x2_f32 and is itself oracle-checked bit for bit in test_gpu_parity.py / test_gpu_properties.py."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mmf():
+    import multimodal_fusion_amd as m
+    assert torch.cuda.is_available()
+    return m
+
+
+def make(n, d, seed, block=65536):
+    out = torch.empty((n, d), dtype=torch.float32, device="cuda")
+    for b in range(0, n, block):
+        g = torch.Generator(device="cuda").manual_seed(seed + b)
+        x = torch.randn((min(block, n - b), d), generator=g, device="cuda", dtype=torch.float32)
+        out[b:b + x.shape[0]] = x / x.norm(dim=1, keepdim=True)
+    return out
+
+
+def oracle_on_rows(X, Y, rows, k, metric, exclude_self, lam=1.0):
+    """Oracle top-k of the given (scattered) rows in ONE call: the rows are packed into a small matrix, ranked
+    against all columns WITHOUT self exclusion at k + 1, and self is then dropped by identity — the ranking is a
+    total order (key desc, id asc), so this equals the oracle's own exclude_self result."""
+    Yh = (X if Y is None else Y).float().cpu().numpy()
+    Xs = X[rows].float().cpu().numpy()
+    kk = k + (1 if exclude_self else 0)
+    ri, rv = oracle.simtopk(Xs, Yh, metric=metric, lam=lam, k=kk, exclude_self=False)
+    if not exclude_self:
+        return ri, rv
+    oi = np.empty((len(rows), k), dtype=np.int64)
+    ov = np.empty((len(rows), k), dtype=np.float32)
+    rr = rows.cpu().numpy()
+    for a in range(len(rr)):
+        keep = ri[a] != rr[a]
+        oi[a] = ri[a][keep][:k]
+        ov[a] = rv[a][keep][:k]
+    return oi, ov
+
+
+def spread_rows(n, count=256):
+    """`count` rows spread over all row blocks of the matrix, at varying positions inside the 256-query tiles."""
+    step = n // count
+    i = torch.arange(count, device="cuda")
+    return (i * step + (i * 37) % step).long()
+
+
+def whole_result(mmf, X, Y, metric, k, exclude_self, precisions=("fast", "fast_bf16"), lam=1.0, oracle_rows=256):
+    ei, ev, est = mmf.simtopk(X, Y, metric=metric, lam=lam, k=k, exclude_self=exclude_self, precision="exact", return_stats=True)
+    assert est["precision_used"] == 1
+    for prec in precisions:
+        fi, fv, st = mmf.simtopk(X, Y, metric=metric, lam=lam, k=k, exclude_self=exclude_self, precision=prec, return_stats=True)
+        assert st["precision_used"] == (2 if prec == "fast" else 3)
+        bad = (fi != ei).any(dim=1) | (fv != ev).any(dim=1)
+        assert not bool(bad.any()), f"{prec}: {int(bad.sum())} of {X.shape[0]} rows differ from the exact scan, first {int(torch.nonzero(bad)[0])}"
+    rows = spread_rows(X.shape[0], oracle_rows)
+    oi, ov = oracle_on_rows(X, Y, rows, k, metric, exclude_self, lam)
+    assert np.array_equal(ei[rows].cpu().numpy(), oi), "indices differ from the oracle"
+    if metric == "rbf":
+        np.testing.assert_allclose(ev[rows].cpu().numpy(), ov, rtol=0, atol=1e-5)    # expf: device vs libm, ulps
+    else:
+        assert np.array_equal(ev[rows].cpu().numpy(), ov), "scores differ from the oracle"
+    return ei, ev
+
+
+def test_c4_headline_workload_every_row(mmf):
+    """BASELINE C4 / the bench workload: N = 262144, d = 512, cosine, k = 5, self excluded."""
+    from test_gpu_configs import check_against_torch, check_properties
+    X = make(262144, 512, 1234)
+    ei, ev = whole_result(mmf, X, None, "cosine", 5, True)
+    check_properties(ei, ev, 262144, 262144, 0, True)
+    check_against_torch(X, None, ei, ev, 5, True)
+
+
+@pytest.mark.parametrize("metric", ["cosine", "neg_sq_l2", "rbf"])
+def test_c2_every_row(mmf, metric):
+    X = make(65536, 512, 99)
+    whole_result(mmf, X, None, metric, 5, True, oracle_rows=128)
+
+
+def test_c3_cross_modal_every_row(mmf):
+    X, Y = make(65536, 512, 1234), make(65536, 512, 4321)
+    whole_result(mmf, X, Y, "cosine", 5, False, oracle_rows=128)
+
+
+def test_d1024_fp16_features_every_row(mmf):
+    """The 4-wave d <= 1024 variant of the scan (BASELINE C5's shape) at N = 131072, fp16 features."""
+    X = make(131072, 1024, 5).half()
+    whole_result(mmf, X, None, "cosine", 5, True, oracle_rows=64)
+
+
+def test_k16_and_clustered_rows_every_row(mmf):
+    """The 16-entry-list variant (k + self = 17) and near-duplicate data (overflow lists) against the exact scan."""
+    X = make(65536, 512, 77)
+    whole_result(mmf, X, None, "cosine", 16, True, precisions=("fast",), oracle_rows=64)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    centers = make(512, 512, 3)
+    assign = torch.randint(0, 512, (65536,), generator=g, device="cuda")
+    Xc = centers[assign] + 0.01 * torch.randn((65536, 512), generator=g, device="cuda") / 512 ** 0.5
+    Xc = Xc / Xc.norm(dim=1, keepdim=True)
+    whole_result(mmf, Xc, None, "neg_sq_l2", 5, True, oracle_rows=64)
