@@ -244,6 +244,19 @@ int mmf_sim_dense(const void* X, int64_t n, const void* Y, int64_t m, int64_t d,
                   int device_id, void* hip_stream);
 
 /*
+ * mmf_sim_dense plus the five statistics the reference takes of such a matrix — mean, std (unbiased), min, max,
+ * lower median, as device double[5] — replacing the `.mean()/.std()/.min()/.max()/.median()` passes of
+ * compute_wsi_tma_similarity (build_hypergraph/preprocess_hypergraph.py:259-265).
+ * MMF_RBF_DIRECT: the sums, minimum and maximum come out of the epilogue of the kernel that forms S (no extra pass);
+ * the median is a 4-pass radix select over S.  out == NULL (MMF_RBF_DIRECT only): S is never stored — its rows are
+ * recomputed in panels of `panel_rows` rows (0 = about 1 GiB) for every radix pass.
+ * Other metrics: mmf_sim_dense followed by mmf_array_stats.   n, m >= 1.
+ */
+int mmf_sim_dense_stats(const void* X, int64_t n, const void* Y, int64_t m, int64_t d,
+                        int in_dtype, int metric, float lambda, float* out, double* out_stats,
+                        int64_t panel_rows, int device_id, void* hip_stream);
+
+/*
  * Dense combined similarity K = K_h * K_g in one pass (no K_h / K_g temporaries).
  * Replaces: compute_combined_similarity, build_hypergraph/similarity_kernel.py:88-124.
  * F:[n,d] features, P:[n,dp] positions (dp = 2 or 3, any dp >= 1 accepted), both f32.
@@ -271,6 +284,19 @@ int mmf_threshold_edges(const float* K, int64_t n, float threshold,
                         int64_t* out_count, int device_id, void* hip_stream);
 
 /*
+ * Order statistics of a flat f32 array already in HBM (any dense similarity matrix, or a vector of edge weights).
+ *   mmf_lower_median: element (count-1)/2 of the sorted values = torch.median — the edge-weight median filter of
+ *                     rebuild_hypergraph_from_similarity, build_hypergraph/preprocess_hypergraph.py:885-897.
+ *   mmf_array_stats:  out_stats (device double[5]) = mean, std (unbiased, torch.std), min, max, lower median —
+ *                     the similarity statistics of preprocess_hypergraph.py:186-197, 259-265, 849-855 — in one
+ *                     reduction pass (f64 accumulation around a pivot, fixed merge order: bit-reproducible) plus
+ *                     the 4-pass radix select, instead of five torch reductions and a full sort.
+ * count < 1 -> MMF_E_INVALID.
+ */
+int mmf_lower_median(const float* v, int64_t count, float* out_median, int device_id, void* hip_stream);
+int mmf_array_stats(const float* v, int64_t count, double* out_stats, int device_id, void* hip_stream);
+
+/*
  * The same two steps for an N whose combined similarity K = K_h * K_g ([n,n] f32) does not fit in
  * memory: K is recomputed from (F, P) in row panels of `panel_rows` rows (0 = about 1 GiB per panel) — four sweeps
  * for the median (one per radix byte), one sweep per call of the edge builder (capacity 0 counts, then fill).
@@ -283,6 +309,38 @@ int mmf_combined_threshold_edges(const float* F, const float* P, int64_t n, int6
                                  float lambda_h, float lambda_g, float threshold, int64_t panel_rows,
                                  int64_t* edge_index, float* edge_w, int64_t capacity, int64_t* out_count,
                                  int device_id, void* hip_stream);
+
+/*
+ * Cluster-shaped steps around the similarity kernels: what the reference does with a vector
+ * of KMeans labels in Python loops.  labels / order / offsets / counts / pairs are int64 device arrays (torch.long);
+ * at most 16384 segments.
+ *   mmf_segment_sort          labels[n] in [0, S) -> counts[S], offsets[S+1] (exclusive scan), order[n] = the rows of
+ *                             segment 0, then 1, ... each in ascending row order (stable counting sort).  A label
+ *                             outside [0, S) -> MMF_E_INVALID.  Host-synchronous (reads that one flag back).
+ *   mmf_segment_mean          out[S, d] = mean of the rows of X[n, d] in each segment, summed in member order:
+ *                             the per-cluster `features[mask].mean(0)` loop, preprocess_hypergraph.py:157-170.
+ *   mmf_segment_offdiag_mean  out_mean[S] (double) = mean of K[i][j] over the ordered pairs i != j of a segment's
+ *                             members (NaN for segments with fewer than two): the K[idx][:, idx] off-diagonal means
+ *                             of preprocess_hypergraph.py:175-184, by direct gathers (no cancellation).
+ *   mmf_clique_pairs          every pair (a < b) inside every segment — the m(m-1) ordered pairs of :395-400 after the
+ *                             undirected dedup of :403 — cluster by cluster; writes at most `capacity` pairs, always
+ *                             the true count to *out_count (capacity 0 = count only).
+ *   mmf_knn_pairs             nbr[n, k] (neighbour ids, self already excluded) -> the undirected pairs (min, max) of
+ *                             :386-388 without duplicates: a pair is dropped when both rows emit it (kept from the
+ *                             smaller row) or when `labels` (may be NULL) puts both ends in one segment, i.e. a clique
+ *                             already holds it.  pair_lo / pair_hi need room for n * k; order unspecified.
+ */
+int mmf_segment_sort(const int64_t* labels, int64_t n, int64_t n_segments, int64_t* counts, int64_t* offsets,
+                     int64_t* order, int device_id, void* hip_stream);
+int mmf_segment_mean(const float* X, int64_t n, int64_t d, const int64_t* order, const int64_t* offsets,
+                     int64_t n_segments, float* out, int device_id, void* hip_stream);
+int mmf_segment_offdiag_mean(const float* K, int64_t n, const int64_t* order, const int64_t* offsets,
+                             int64_t n_segments, double* out_mean, int device_id, void* hip_stream);
+int mmf_clique_pairs(const int64_t* order, const int64_t* offsets, int64_t n, int64_t n_segments,
+                     int64_t* pair_lo, int64_t* pair_hi, int64_t capacity, int64_t* out_count,
+                     int device_id, void* hip_stream);
+int mmf_knn_pairs(const int64_t* nbr, int64_t n, int k, const int64_t* labels,
+                  int64_t* pair_lo, int64_t* pair_hi, int64_t* out_count, int device_id, void* hip_stream);
 
 /* Release the library's cached per-device workspaces (they are grow-only otherwise). */
 int mmf_release_workspaces(void);

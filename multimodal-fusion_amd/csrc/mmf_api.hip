@@ -759,6 +759,62 @@ int mmf_sim_dense(const void* X, int64_t n, const void* Y, int64_t m, int64_t d,
   return launch_sim_dense(X, n, Y, m, d, in_dtype, metric, lambda, rx, cy, out, s);
 }
 
+int mmf_sim_dense_stats(const void* X, int64_t n, const void* Y, int64_t m, int64_t d, int in_dtype, int metric, float lambda,
+                        float* out, double* out_stats, int64_t panel_rows, int device_id, void* hip_stream) {
+  if (!Y) { Y = X; m = n; }
+  MMF_TRY(check_common(X, n, m, d, in_dtype, device_id));
+  if (metric < MMF_DOT || metric > MMF_RBF_DIRECT) { set_error("sim_dense_stats: bad metric %d", metric); return MMF_E_INVALID; }
+  if (n < 1 || m < 1) { set_error("sim_dense_stats: empty matrix"); return MMF_E_INVALID; }
+  if (!out_stats) { set_error("sim_dense_stats: NULL out_stats"); return MMF_E_INVALID; }
+  if (!out && metric != MMF_RBF_DIRECT) { set_error("sim_dense_stats: out == NULL is supported for MMF_RBF_DIRECT only"); return MMF_E_UNSUPPORTED; }
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const int64_t count = n * m;
+  if (metric != MMF_RBF_DIRECT) {        // matrix-core dense kernels, then one reduction pass + the radix select
+    MMF_TRY(mmf_sim_dense(X, n, Y, m, d, in_dtype, metric, lambda, out, device_id, hip_stream));
+    return mmf_array_stats(out, count, out_stats, device_id, hip_stream);
+  }
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  int64_t R = n;
+  if (!out) {                            // nothing stored: rows recomputed in panels for each radix pass
+    R = panel_rows > 0 ? panel_rows : (int64_t(1) << 30) / (4 * m);
+    R = (R + 127) / 128 * 128;
+    if (R < 128) R = 128;
+    if (R > n) R = n;
+  }
+  int64_t blocks = 0;
+  for (int64_t r0 = 0; r0 < n; r0 += R) blocks += rbf_direct_blocks((n - r0 < R) ? (n - r0) : R, m);
+  Workspace ws;
+  MMF_TRY(get_workspace(device_id, s, ws_bytes((size_t)blocks * stat_partial_bytes(), 1) + ws_bytes(64, 4) + ws_bytes(median_state_bytes(), 1) +
+                                      (out ? 0 : ws_bytes((size_t)R * m, 4)), &ws));
+  char* part = ws.take<char>((size_t)blocks * stat_partial_bytes());
+  float* pivot = ws.take<float>(64);
+  float* med = pivot + 8;
+  void* mstate = ws.take<char>(median_state_bytes());
+  MMF_TRY(launch_rbf_direct_pivot(X, Y, d, in_dtype, lambda, pivot, s));
+  if (out) {
+    MMF_TRY(launch_rbf_direct(X, n, Y, m, d, in_dtype, lambda, out, part, pivot, s));
+    MMF_TRY(launch_lower_median(out, count, med, mstate, s));
+  } else {
+    float* panel = ws.take<float>((size_t)R * m);
+    MMF_TRY(launch_median_begin_count(mstate, (unsigned long long)count, s));
+    for (int pass = 0; pass < 4; ++pass) {
+      int64_t b0 = 0;
+      for (int64_t r0 = 0; r0 < n; r0 += R) {
+        const int64_t rows = (n - r0 < R) ? (n - r0) : R;
+        const void* Xp = static_cast<const char*>(X) + (size_t)r0 * d * dtype_size(in_dtype);
+        MMF_TRY(launch_rbf_direct(Xp, rows, Y, m, d, in_dtype, lambda, panel,
+                                  pass == 0 ? part + (size_t)b0 * stat_partial_bytes() : nullptr, pivot, s));
+        MMF_TRY(launch_median_accumulate_flat(panel, m, rows, mstate, pass, s));
+        b0 += rbf_direct_blocks(rows, m);
+      }
+      MMF_TRY(launch_median_next(mstate, pass, med, s));
+    }
+  }
+  MMF_TRY(launch_stats_finish(part, blocks, pivot, count, out_stats, s));
+  return launch_stats_set_median(med, out_stats, s);
+}
+
 int mmf_sim_dense_combined(const float* F, const float* P, int64_t n, int64_t d, int64_t dp, float lambda_h,
                            float lambda_g, float* out, int device_id, void* hip_stream) {
   MMF_TRY(check_common(F, n, n, d, MMF_F32, device_id));
@@ -785,6 +841,109 @@ int mmf_offdiag_lower_median(const float* K, int64_t n, float* out_median, int d
   Workspace ws;
   MMF_TRY(get_workspace(device_id, s, ws_bytes(4096, 4), &ws));
   return launch_offdiag_lower_median(K, n, out_median, ws.take<uint32_t>(4096), s);
+}
+
+// ---- cluster-shaped steps (mmf_segments.hip) ----------------------------------------------------------------------
+static int seg_common(const char* what, int64_t n, int64_t S, int device_id) {
+  if (device_id < 0) { set_error("%s: no CPU path", what); return MMF_E_UNSUPPORTED; }
+  if (n < 0 || S < 1) { set_error("%s: bad n / n_segments", what); return MMF_E_INVALID; }
+  if (S > segment_max_segments()) { set_error("%s: at most %d segments are supported (got %lld)", what, segment_max_segments(), (long long)S); return MMF_E_UNSUPPORTED; }
+  return MMF_OK;
+}
+
+int mmf_segment_sort(const int64_t* labels, int64_t n, int64_t n_segments, int64_t* counts, int64_t* offsets, int64_t* order,
+                     int device_id, void* hip_stream) {
+  MMF_TRY(seg_common("segment_sort", n, n_segments, device_id));
+  if (!counts || !offsets || (n > 0 && (!labels || !order))) { set_error("segment_sort: NULL pointer"); return MMF_E_INVALID; }
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  if (n == 0) {
+    MMF_HIP(hipMemsetAsync(counts, 0, (size_t)n_segments * 8, s));
+    MMF_HIP(hipMemsetAsync(offsets, 0, (size_t)(n_segments + 1) * 8, s));
+    return MMF_OK;
+  }
+  Workspace ws;
+  MMF_TRY(get_workspace(device_id, s, ws_bytes(segment_sort_scratch_bytes(n, n_segments), 1) + ws_bytes(4, 4), &ws));
+  char* scratch = ws.take<char>(segment_sort_scratch_bytes(n, n_segments));
+  uint32_t* bad = ws.take<uint32_t>(4);
+  MMF_TRY(launch_segment_sort(labels, n, n_segments, counts, offsets, order, scratch, bad, s));
+  uint32_t h_bad = 0;
+  MMF_HIP(hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, s));
+  MMF_HIP(hipStreamSynchronize(s));
+  if (h_bad) { set_error("segment_sort: %u labels lie outside [0, %lld)", h_bad, (long long)n_segments); return MMF_E_INVALID; }
+  return MMF_OK;
+}
+
+int mmf_segment_mean(const float* X, int64_t n, int64_t d, const int64_t* order, const int64_t* offsets, int64_t n_segments,
+                     float* out, int device_id, void* hip_stream) {
+  MMF_TRY(seg_common("segment_mean", n, n_segments, device_id));
+  if (d < 1) { set_error("segment_mean: d < 1"); return MMF_E_INVALID; }
+  if (!X || !order || !offsets || !out) { set_error("segment_mean: NULL pointer"); return MMF_E_INVALID; }
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  return launch_segment_mean(X, d, order, offsets, n_segments, out, static_cast<hipStream_t>(hip_stream));
+}
+
+int mmf_segment_offdiag_mean(const float* K, int64_t n, const int64_t* order, const int64_t* offsets, int64_t n_segments,
+                             double* out_mean, int device_id, void* hip_stream) {
+  MMF_TRY(seg_common("segment_offdiag_mean", n, n_segments, device_id));
+  if (n < 1 || !K || !order || !offsets || !out_mean) { set_error("segment_offdiag_mean: NULL pointer / empty matrix"); return MMF_E_INVALID; }
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  Workspace ws;
+  MMF_TRY(get_workspace(device_id, s, segment_offdiag_scratch_bytes(n), &ws));
+  return launch_segment_offdiag_mean(K, n, order, offsets, n_segments, out_mean, ws.take<char>(segment_offdiag_scratch_bytes(n)), s);
+}
+
+int mmf_clique_pairs(const int64_t* order, const int64_t* offsets, int64_t n, int64_t n_segments, int64_t* pair_lo,
+                     int64_t* pair_hi, int64_t capacity, int64_t* out_count, int device_id, void* hip_stream) {
+  MMF_TRY(seg_common("clique_pairs", n, n_segments, device_id));
+  if (capacity < 0 || !offsets || !out_count || (n > 0 && !order) || (capacity > 0 && (!pair_lo || !pair_hi))) {
+    set_error("clique_pairs: NULL pointer / bad capacity"); return MMF_E_INVALID;
+  }
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  Workspace ws;
+  MMF_TRY(get_workspace(device_id, s, clique_scratch_bytes(n, n_segments), &ws));
+  return launch_clique_pairs(order, offsets, n, n_segments, pair_lo, pair_hi, capacity, out_count,
+                             ws.take<char>(clique_scratch_bytes(n, n_segments)), s);
+}
+
+int mmf_knn_pairs(const int64_t* nbr, int64_t n, int k, const int64_t* labels, int64_t* pair_lo, int64_t* pair_hi,
+                  int64_t* out_count, int device_id, void* hip_stream) {
+  if (device_id < 0) { set_error("knn_pairs: no CPU path"); return MMF_E_UNSUPPORTED; }
+  if (n < 0 || k < 1) { set_error("knn_pairs: bad n / k"); return MMF_E_INVALID; }
+  if (!out_count || (n > 0 && (!nbr || !pair_lo || !pair_hi))) { set_error("knn_pairs: NULL pointer"); return MMF_E_INVALID; }
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  return launch_knn_pairs(nbr, n, k, labels, pair_lo, pair_hi, out_count, static_cast<hipStream_t>(hip_stream));
+}
+
+int mmf_lower_median(const float* v, int64_t count, float* out_median, int device_id, void* hip_stream) {
+  if (device_id < 0) { set_error("lower_median: no CPU path"); return MMF_E_UNSUPPORTED; }
+  if (count < 1) { set_error("lower_median: need count >= 1 (got %lld)", (long long)count); return MMF_E_INVALID; }
+  if (!v || !out_median) { set_error("lower_median: NULL pointer"); return MMF_E_INVALID; }
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  Workspace ws;
+  MMF_TRY(get_workspace(device_id, s, ws_bytes(median_state_bytes(), 1), &ws));
+  return launch_lower_median(v, count, out_median, ws.take<char>(median_state_bytes()), s);
+}
+
+int mmf_array_stats(const float* v, int64_t count, double* out_stats, int device_id, void* hip_stream) {
+  if (device_id < 0) { set_error("array_stats: no CPU path"); return MMF_E_UNSUPPORTED; }
+  if (count < 1) { set_error("array_stats: need count >= 1 (got %lld)", (long long)count); return MMF_E_INVALID; }
+  if (!v || !out_stats) { set_error("array_stats: NULL pointer"); return MMF_E_INVALID; }
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  Workspace ws;
+  MMF_TRY(get_workspace(device_id, s, ws_bytes(array_stats_scratch_bytes(), 1), &ws));
+  return launch_array_stats(v, count, out_stats, ws.take<char>(array_stats_scratch_bytes()), s);
 }
 
 int mmf_threshold_edges(const float* K, int64_t n, float threshold, int64_t* edge_index, float* edge_w,

@@ -105,11 +105,13 @@ int launch_offdiag_lower_median(const float* K, int64_t n, float* out, uint32_t*
 // The same radix select in pieces, for matrices that are recomputed panel by panel instead of stored:
 // begin; then for pass 0..3 { accumulate every panel; next }.  `out` is written by next(pass 3).
 size_t median_state_bytes() { return sizeof(MedianState); }
-int launch_median_begin(void* state, int64_t n, hipStream_t s) {
-  const unsigned long long cnt = (unsigned long long)n * (unsigned long long)(n - 1);
+int launch_median_begin_count(void* state, unsigned long long cnt, hipStream_t s) {
   hipLaunchKernelGGL(median_init_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<MedianState*>(state), (cnt - 1) / 2);
   MMF_LAUNCH_CHECK();
   return MMF_OK;
+}
+int launch_median_begin(void* state, int64_t n, hipStream_t s) {
+  return launch_median_begin_count(state, (unsigned long long)n * (unsigned long long)(n - 1), s);
 }
 int launch_median_accumulate(const float* K, int64_t n, int64_t row0, int64_t rows, void* state, int pass, hipStream_t s) {
   if (rows <= 0) return MMF_OK;
@@ -123,6 +125,128 @@ int launch_median_next(void* state, int pass, float* out, hipStream_t s) {
   hipLaunchKernelGGL(median_pick_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<MedianState*>(state), 24 - 8 * pass, out);
   MMF_LAUNCH_CHECK();
   return MMF_OK;
+}
+
+// Lower median (torch.median semantics: element (count - 1) / 2 of the sorted values) of a flat array — the
+// similarity statistics of preprocess_hypergraph.py:190-196, 259-265 and the edge-weight median of :885-897.
+// The array is walked as rows of 4096 values (plus one ragged row) by the same histogram kernel; a row0 that no
+// column index can reach switches the diagonal skip off.
+constexpr int64_t kNoDiagonal = -(int64_t(1) << 62);
+int launch_lower_median(const float* v, int64_t count, float* out, void* state, hipStream_t s) {
+  MMF_TRY(launch_median_begin_count(state, (unsigned long long)count, s));
+  const int64_t C = 4096, full = count / C, tail = count - full * C;
+  for (int pass = 0; pass < 4; ++pass) {
+    if (full > 0) MMF_TRY(launch_median_accumulate(v, C, kNoDiagonal, full, state, pass, s));
+    if (tail > 0) MMF_TRY(launch_median_accumulate(v + full * C, tail, kNoDiagonal, 1, state, pass, s));
+    MMF_TRY(launch_median_next(state, pass, out, s));
+  }
+  return MMF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// mean / std / min / max of a flat f32 array in ONE pass (f64 accumulation around a pivot), deterministic:
+// every workgroup writes its partial, one workgroup merges them in index order.
+// Replaces: K.mean(), K.std(), K.min(), K.max() — four passes — at preprocess_hypergraph.py:190-195, 260-263.
+// ------------------------------------------------------------------------------------------------
+struct StatPartial { double s1, s2; float mn, mx; };
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+
+__global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restrict__ v, int64_t count, StatPartial* __restrict__ part) {
+  const double p = (double)v[0];                       // pivot: sums of (x - p) stay small when the values cluster
+  double s1 = 0.0, s2 = 0.0;
+  float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
+  auto feed = [&](float x) {
+    const double dx = (double)x - p;
+    s1 += dx; s2 = __builtin_fma(dx, dx, s2);
+    mn = fminf(mn, x); mx = fmaxf(mx, x);
+  };
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  const int64_t n4 = ((reinterpret_cast<uintptr_t>(v) & 15) == 0) ? (count >> 2) : 0;
+  for (int64_t i = tid; i < n4; i += nth) {
+    const f32x4 x = reinterpret_cast<const f32x4*>(v)[i];
+    feed(x[0]); feed(x[1]); feed(x[2]); feed(x[3]);
+  }
+  for (int64_t i = n4 * 4 + tid; i < count; i += nth) feed(v[i]);
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+  __shared__ StatPartial w[4];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) w[wave] = StatPartial{s1, s2, mn, mx};
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    StatPartial r = w[0];
+    for (int i = 1; i < 4; ++i) { r.s1 += w[i].s1; r.s2 += w[i].s2; r.mn = fminf(r.mn, w[i].mn); r.mx = fmaxf(r.mx, w[i].mx); }
+    part[blockIdx.x] = r;
+  }
+}
+
+// out[0..3] = mean, std (unbiased, as torch.std), min, max; out[4] is the median's slot.  pivot[0]: the value the
+// partial sums were taken around.
+__global__ __launch_bounds__(256) void stats_final_kernel(const float* __restrict__ pivot, int64_t count, const StatPartial* __restrict__ part,
+                                                          int64_t nparts, double* __restrict__ out) {
+  __shared__ StatPartial w[256];
+  StatPartial r{0.0, 0.0, __builtin_huge_valf(), -__builtin_huge_valf()};
+  for (int64_t i = threadIdx.x; i < nparts; i += 256) {   // fixed assignment, fixed order: bit-reproducible
+    r.s1 += part[i].s1; r.s2 += part[i].s2; r.mn = fminf(r.mn, part[i].mn); r.mx = fmaxf(r.mx, part[i].mx);
+  }
+  w[threadIdx.x] = r;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      w[threadIdx.x].s1 += w[threadIdx.x + o].s1; w[threadIdx.x].s2 += w[threadIdx.x + o].s2;
+      w[threadIdx.x].mn = fminf(w[threadIdx.x].mn, w[threadIdx.x + o].mn); w[threadIdx.x].mx = fmaxf(w[threadIdx.x].mx, w[threadIdx.x + o].mx);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double n = (double)count, p = (double)pivot[0];
+    const double mean = p + w[0].s1 / n;
+    double var = (w[0].s2 - w[0].s1 * w[0].s1 / n) / (n - 1.0);   // count == 1: 0 / 0 = NaN, as torch.std
+    if (var < 0.0) var = 0.0;
+    out[0] = mean; out[1] = __builtin_sqrt(var); out[2] = (double)w[0].mn; out[3] = (double)w[0].mx;
+  }
+}
+
+__global__ void stats_median_kernel(const float* med, double* out) { out[4] = (double)*med; }
+
+size_t array_stats_scratch_bytes() { return 2048 * sizeof(StatPartial) + sizeof(MedianState) + 256; }
+
+int launch_array_stats(const float* v, int64_t count, double* out, void* scratch, hipStream_t s) {
+  StatPartial* part = reinterpret_cast<StatPartial*>(scratch);
+  char* rest = reinterpret_cast<char*>(scratch) + 2048 * sizeof(StatPartial);
+  float* med = reinterpret_cast<float*>(rest);
+  void* mstate = rest + 256;
+  int64_t grid = (count + 256 * 16 - 1) / (256 * 16);
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(stats_partial_kernel, dim3((unsigned)grid), dim3(256), 0, s, v, count, part);
+  MMF_LAUNCH_CHECK();
+  MMF_TRY(launch_stats_finish(part, grid, v, count, out, s));
+  MMF_TRY(launch_lower_median(v, count, med, mstate, s));
+  return launch_stats_set_median(med, out, s);
+}
+
+// the merge of per-workgroup partials (StatPartial: {double s1, s2; float mn, mx}) written by ANY producer kernel
+int launch_stats_finish(const void* part, int64_t nparts, const float* pivot, int64_t count, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(256), 0, s, pivot, count, reinterpret_cast<const StatPartial*>(part), nparts, out);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+int launch_stats_set_median(const float* med, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(stats_median_kernel, dim3(1), dim3(1), 0, s, med, out);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+size_t stat_partial_bytes() { return sizeof(StatPartial); }
+// one radix pass over `rows` rows of `cols` values each (a panel of a rectangular matrix: no diagonal to skip)
+int launch_median_accumulate_flat(const float* K, int64_t cols, int64_t rows, void* state, int pass, hipStream_t s) {
+  return launch_median_accumulate(K, cols, kNoDiagonal, rows, state, pass, s);
 }
 
 // ------------------------------------------------------------------------------------------------

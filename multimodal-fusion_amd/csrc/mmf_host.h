@@ -162,11 +162,40 @@ size_t median_state_bytes();
 int launch_median_begin(void* state, int64_t n, hipStream_t s);
 int launch_median_accumulate(const float* K, int64_t n, int64_t row0, int64_t rows, void* state, int pass, hipStream_t s);
 int launch_median_next(void* state, int pass, float* out, hipStream_t s);
+int launch_median_begin_count(void* state, unsigned long long count, hipStream_t s);
+// lower median of a flat array (state: median_state_bytes()); mean / std / min / max / median of a flat array
+int launch_lower_median(const float* v, int64_t count, float* out, void* state, hipStream_t s);
+int launch_stats_finish(const void* part, int64_t nparts, const float* pivot, int64_t count, double* out, hipStream_t s);
+int launch_stats_set_median(const float* med, double* out, hipStream_t s);
+size_t stat_partial_bytes();
+int launch_median_accumulate_flat(const float* K, int64_t cols, int64_t rows, void* state, int pass, hipStream_t s);
+// mmf_direct.hip: register-tiled direct-difference RBF with optional per-workgroup statistic partials
+int64_t rbf_direct_blocks(int64_t n, int64_t m);
+int launch_rbf_direct_pivot(const void* X, const void* Y, int64_t d, int dtype, float lambda, float* pivot, hipStream_t s);
+int launch_rbf_direct(const void* X, int64_t n, const void* Y, int64_t m, int64_t d, int dtype, float lambda, float* out,
+                      void* part, const float* pivot, hipStream_t s);
+size_t array_stats_scratch_bytes();
+int launch_array_stats(const float* v, int64_t count, double* out /*[5] device*/, void* scratch, hipStream_t s);
 int launch_threshold_edges_panel(const float* K, int64_t n, int64_t row0, int64_t rows, float thr, int64_t* ei_row,
                                  int64_t* ei_col, float* ew, int64_t capacity, int64_t* out_count, uint32_t* scratch,
                                  size_t scratch_u32, hipStream_t s);
 int launch_threshold_edges(const float* K, int64_t n, float thr, int64_t* ei, float* ew,
                            int64_t capacity, int64_t* out_count, uint32_t* scratch, size_t scratch_u32,
                            hipStream_t s);
+
+// mmf_segments.hip: cluster-shaped steps (labels -> members, per-cluster means, cliques, k-NN pair dedup)
+int segment_max_segments();
+size_t segment_sort_scratch_bytes(int64_t n, int64_t S);
+int launch_segment_sort(const int64_t* labels, int64_t n, int64_t S, int64_t* counts, int64_t* offsets, int64_t* order,
+                        void* scratch, uint32_t* bad, hipStream_t s);
+int launch_segment_mean(const float* X, int64_t d, const int64_t* order, const int64_t* offsets, int64_t S, float* out, hipStream_t s);
+size_t segment_offdiag_scratch_bytes(int64_t n);
+int launch_segment_offdiag_mean(const float* K, int64_t n, const int64_t* order, const int64_t* offsets, int64_t S,
+                                double* out_mean, void* scratch, hipStream_t s);
+size_t clique_scratch_bytes(int64_t n, int64_t S);
+int launch_clique_pairs(const int64_t* order, const int64_t* offsets, int64_t n, int64_t S, int64_t* lo, int64_t* hi,
+                        int64_t capacity, int64_t* out_count, void* scratch, hipStream_t s);
+int launch_knn_pairs(const int64_t* nbr, int64_t n, int k, const int64_t* labels, int64_t* lo, int64_t* hi, int64_t* out_count,
+                     hipStream_t s);
 
 }  // namespace mmf

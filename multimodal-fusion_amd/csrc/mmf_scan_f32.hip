@@ -311,42 +311,6 @@ __global__ __launch_bounds__(F_NT, (MODE == MODE_DENSE || CAP <= 16) ? 2 : 1) vo
   }
 }
 
-// direct-difference RBF, preprocess_hypergraph.py:254-256: out = exp(-lambda * sum_k (a_k - b_k)^2)
-__global__ __launch_bounds__(256) void rbf_direct_kernel(const void* __restrict__ X, int64_t n,
-                                                         const void* __restrict__ Y, int64_t m, int64_t d,
-                                                         int dtype, float neg_lambda, float* __restrict__ out) {
-  __shared__ float Xs[32][33];
-  __shared__ float Ys[32][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  const int64_t i0 = (int64_t)blockIdx.y * 32, j0 = (int64_t)blockIdx.x * 32;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t k0 = 0; k0 < d; k0 += 32) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int rr = ty + 8 * r;
-      const int64_t k = k0 + tx;
-      Xs[rr][tx] = (i0 + rr < n && k < d) ? ld_elem(X, (i0 + rr) * d + k, dtype) : 0.0f;
-      Ys[rr][tx] = (j0 + rr < m && k < d) ? ld_elem(Y, (j0 + rr) * d + k, dtype) : 0.0f;
-    }
-    __syncthreads();
-    const int kend = (d - k0 < 32) ? (int)(d - k0) : 32;
-    for (int kk = 0; kk < kend; ++kk) {
-      const float yv = Ys[tx][kk];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float t = Xs[ty + 8 * r][kk] - yv;
-        acc[r] = __builtin_fmaf(t, t, acc[r]);
-      }
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int64_t i = i0 + ty + 8 * r, j = j0 + tx;
-    if (i < n && j < m) out[i * m + j] = expf(neg_lambda * acc[r]);
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 int scan_f32_cap(int kk) {
   if (kk <= 12) return 16;
@@ -460,12 +424,7 @@ int launch_sim_dense(const void* X, int64_t n, const void* Y, int64_t m, int64_t
     MMF_LAUNCH_CHECK();
     return MMF_OK;
   }
-  if (metric == MMF_RBF_DIRECT) {
-    dim3 grid((unsigned)((m + 31) / 32), (unsigned)((n + 31) / 32));
-    hipLaunchKernelGGL(rbf_direct_kernel, grid, dim3(256), 0, s, X, n, Y, m, d, dtype, -lambda, out);
-    MMF_LAUNCH_CHECK();
-    return MMF_OK;
-  }
+  if (metric == MMF_RBF_DIRECT) return launch_rbf_direct(X, n, Y, m, d, dtype, lambda, out, nullptr, nullptr, s);   // mmf_direct.hip
   ScanF32Args a{};
   a.X = X; a.Y = Y; a.n = n; a.m = m; a.d = d; a.dtype = dtype;
   a.rx = rx; a.cy = cy; a.row_ids = nullptr; a.n_rows = n;

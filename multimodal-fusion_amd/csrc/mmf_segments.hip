@@ -1,0 +1,321 @@
+// mmf_segments.hip — the cluster-shaped steps either side of the similarity kernels:
+// everything the reference does with a vector of KMeans labels in Python loops.
+//
+//   segment_sort          labels -> members of every cluster in ascending row order (stable counting sort)
+//   segment_mean          per-cluster mean of rows            preprocess_hypergraph.py:157-170 (mask + mean per cluster)
+//   segment_offdiag_mean  mean off-diagonal similarity inside every cluster   :175-184 (K[idx][:, idx] gathers)
+//   clique_pairs          all pairs inside every cluster      :395-400 (Python triple loop) after the dedup of :403
+//   knn_pairs             undirected, de-duplicated k-NN pairs that no clique already contains   :386-388 + :403
+//
+// All of it is HBM / gather bound integer and f32 work: no matrix cores here.  Every kernel is deterministic
+// (fixed summation order; the one atomic append feeds a sort).
+#include "mmf_dev.h"
+#include "mmf_host.h"
+
+namespace mmf {
+
+constexpr int SEG_CHUNK = 1024;          // labels per single-wave workgroup of the counting sort
+constexpr int SEG_MAX = 16384;           // clusters the LDS histogram holds (64 KiB)
+
+// ---- counting sort ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void seg_count_kernel(const int64_t* __restrict__ labels, int64_t n, int S,
+                                                       uint32_t* __restrict__ block_hist, uint32_t* __restrict__ bad) {
+  extern __shared__ uint32_t hist[];
+  for (int s = threadIdx.x; s < S; s += 64) hist[s] = 0u;
+  __syncthreads();
+  const int64_t b0 = (int64_t)blockIdx.x * SEG_CHUNK;
+  for (int i = threadIdx.x; i < SEG_CHUNK; i += 64) {
+    const int64_t r = b0 + i;
+    if (r < n) {
+      const int64_t l = labels[r];
+      if (l >= 0 && l < S) atomicAdd(&hist[(int)l], 1u);
+      else atomicAdd(bad, 1u);
+    }
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < S; s += 64) block_hist[(size_t)blockIdx.x * S + s] = hist[s];
+}
+
+// per label: exclusive prefix over the blocks (in place), total -> counts
+__global__ void seg_block_scan_kernel(uint32_t* __restrict__ block_hist, int nb, int S, int64_t* __restrict__ counts) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  uint32_t run = 0;
+  for (int b = 0; b < nb; ++b) {
+    const uint32_t t = block_hist[(size_t)b * S + s];
+    block_hist[(size_t)b * S + s] = run;
+    run += t;
+  }
+  counts[s] = (int64_t)run;
+}
+
+// offsets[0..S] = exclusive scan of counts (one workgroup; S <= SEG_MAX)
+__global__ __launch_bounds__(1024) void seg_offsets_kernel(const int64_t* __restrict__ counts, int S, int64_t* __restrict__ offsets) {
+  __shared__ unsigned long long part[1024];
+  const int t = threadIdx.x;
+  const int per = (S + 1023) / 1024;
+  const int b = t * per;
+  int e = b + per;
+  if (e > S) e = S;
+  unsigned long long sum = 0;
+  for (int i = b; i < e; ++i) sum += (unsigned long long)counts[i];
+  part[t] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const unsigned long long v = (t >= o) ? part[t - o] : 0ull;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  unsigned long long run = (t == 0) ? 0ull : part[t - 1];
+  for (int i = b; i < e; ++i) { offsets[i] = (int64_t)run; run += (unsigned long long)counts[i]; }
+  if (t == 1023) offsets[S] = (int64_t)part[1023];
+}
+
+// stable scatter: one wave walks its chunk in row order; lanes that share a label rank themselves with ballots
+__global__ __launch_bounds__(64) void seg_scatter_kernel(const int64_t* __restrict__ labels, int64_t n, int S,
+                                                         const uint32_t* __restrict__ block_hist,
+                                                         const int64_t* __restrict__ offsets, int64_t* __restrict__ order) {
+  extern __shared__ uint32_t cursor[];     // position of the next member of each label, relative to offsets[label]
+  for (int s = threadIdx.x; s < S; s += 64) cursor[s] = block_hist[(size_t)blockIdx.x * S + s];
+  __syncthreads();
+  const int lane = threadIdx.x;
+  const int64_t b0 = (int64_t)blockIdx.x * SEG_CHUNK;
+  for (int i0 = 0; i0 < SEG_CHUNK; i0 += 64) {
+    const int64_t r = b0 + i0 + lane;
+    int l = -1;
+    if (r < n) {
+      const int64_t ll = labels[r];
+      if (ll >= 0 && ll < S) l = (int)ll;
+    }
+    unsigned long long todo = __ballot(l >= 0);
+    while (todo) {
+      const int leader = __builtin_ctzll(todo);
+      const int lead_l = __shfl(l, leader);
+      const unsigned long long m = __ballot(l == lead_l);
+      if (l == lead_l) {
+        const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        order[offsets[l] + (int64_t)(cursor[l] + rank)] = r;
+      }
+      __syncthreads();                 // one wave per workgroup: orders the LDS read above before the update below
+      if (lane == leader) cursor[lead_l] += (uint32_t)__popcll(m);
+      __syncthreads();
+      todo &= ~m;
+    }
+  }
+}
+
+size_t segment_sort_scratch_bytes(int64_t n, int64_t S) {
+  const int64_t nb = (n + SEG_CHUNK - 1) / SEG_CHUNK;
+  return (size_t)nb * (size_t)S * 4 + 256;
+}
+
+int launch_segment_sort(const int64_t* labels, int64_t n, int64_t S, int64_t* counts, int64_t* offsets, int64_t* order,
+                        void* scratch, uint32_t* bad, hipStream_t s) {
+  const int nb = (int)((n + SEG_CHUNK - 1) / SEG_CHUNK);
+  uint32_t* block_hist = reinterpret_cast<uint32_t*>(scratch);
+  const size_t lds = (size_t)S * 4;
+  MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seg_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  MMF_HIP(hipMemsetAsync(bad, 0, 4, s));
+  hipLaunchKernelGGL(seg_count_kernel, dim3((unsigned)nb), dim3(64), lds, s, labels, n, (int)S, block_hist, bad);
+  MMF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(seg_block_scan_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, s, block_hist, nb, (int)S, counts);
+  MMF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(seg_offsets_kernel, dim3(1), dim3(1024), 0, s, counts, (int)S, offsets);
+  MMF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(seg_scatter_kernel, dim3((unsigned)nb), dim3(64), lds, s, labels, n, (int)S, block_hist, offsets, order);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+
+// ---- per-cluster mean of rows -----------------------------------------------------------------------------------
+// Workgroup = (cluster, strip of 64 columns); wave w adds the cluster's rows w, w + 4, ... in member order, the four
+// partial sums are combined in wave order: one fixed summation order, coalesced 256-byte row segments.
+__global__ __launch_bounds__(256) void seg_mean_kernel(const float* __restrict__ X, int64_t d, const int64_t* __restrict__ order,
+                                                       const int64_t* __restrict__ offsets, float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x;
+  const int64_t col = (int64_t)blockIdx.y * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  const int64_t b = offsets[c], e = offsets[c + 1];
+  float acc = 0.f;
+  if (col < d)
+    for (int64_t q = b + w; q < e; q += 4) acc += X[order[q] * d + col];
+  part[w][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (w == 0 && col < d) {
+    const float sum = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+    out[(int64_t)c * d + col] = sum / (float)(e - b);            // empty cluster: 0 / 0 = NaN (the caller rejects it first)
+  }
+}
+
+int launch_segment_mean(const float* X, int64_t d, const int64_t* order, const int64_t* offsets, int64_t S, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(seg_mean_kernel, dim3((unsigned)S, (unsigned)((d + 63) / 64)), dim3(256), 0, s, X, d, order, offsets, out);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+
+// ---- mean off-diagonal similarity inside every cluster ------------------------------------------------------------
+// row_sum[q] = sum over the other members b of K[member q][member b] (one wave per member, f64, lane-strided then a
+// fixed butterfly); cluster mean = (sum of its row sums in member order) / (m (m - 1)).  Direct gathers: no
+// "block sum minus diagonal" cancellation.
+__global__ __launch_bounds__(256) void seg_row_sums_kernel(const float* __restrict__ K, int64_t n, const int64_t* __restrict__ order,
+                                                           const int64_t* __restrict__ offsets, const int32_t* __restrict__ seg_of,
+                                                           int64_t total, double* __restrict__ row_sum) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= total) return;
+  const int c = seg_of[q];
+  const int64_t b = offsets[c], e = offsets[c + 1];
+  const float* row = K + order[q] * n;
+  double acc = 0.0;
+  for (int64_t p = b + lane; p < e; p += 64)
+    if (p != q) acc += (double)row[order[p]];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) row_sum[q] = acc;
+}
+
+__global__ void seg_of_kernel(const int64_t* __restrict__ offsets, int S, int32_t* __restrict__ seg_of) {
+  const int c = blockIdx.x;
+  if (c >= S) return;
+  for (int64_t q = offsets[c] + threadIdx.x; q < offsets[c + 1]; q += blockDim.x) seg_of[q] = c;
+}
+
+__global__ void seg_offdiag_final_kernel(const double* __restrict__ row_sum, const int64_t* __restrict__ offsets, int S,
+                                         double* __restrict__ out_mean) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= S) return;
+  const int64_t b = offsets[c], e = offsets[c + 1], m = e - b;
+  if (m <= 1) { out_mean[c] = __builtin_nan(""); return; }       // the reference skips such clusters (:178)
+  double sum = 0.0;
+  for (int64_t q = b; q < e; ++q) sum += row_sum[q];
+  out_mean[c] = sum / ((double)m * (double)(m - 1));
+}
+
+size_t segment_offdiag_scratch_bytes(int64_t n) { return ws_bytes((size_t)n, 8) + ws_bytes((size_t)n, 4); }
+
+int launch_segment_offdiag_mean(const float* K, int64_t n, const int64_t* order, const int64_t* offsets, int64_t S,
+                                double* out_mean, void* scratch, hipStream_t s) {
+  double* row_sum = reinterpret_cast<double*>(scratch);
+  int32_t* seg_of = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(scratch) + ws_bytes((size_t)n, 8));
+  hipLaunchKernelGGL(seg_of_kernel, dim3((unsigned)S), dim3(256), 0, s, offsets, (int)S, seg_of);
+  MMF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(seg_row_sums_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, K, n, order, offsets, seg_of, n, row_sum);
+  MMF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(seg_offdiag_final_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, s, row_sum, offsets, (int)S, out_mean);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+
+// ---- clique expansion -----------------------------------------------------------------------------------------------
+// Cluster c with members r_0 < r_1 < ... contributes the pairs (r_a, r_b), a < b — what `set(tuple(sorted(e)))` leaves of
+// the reference's m (m - 1) ordered pairs (:395-404).  pair_off[c] = pairs of the clusters before c.
+__global__ __launch_bounds__(1024) void clique_offsets_kernel(const int64_t* __restrict__ offsets, int S,
+                                                              unsigned long long* __restrict__ pair_off, int64_t* __restrict__ out_count) {
+  __shared__ unsigned long long part[1024];
+  const int t = threadIdx.x;
+  const int per = (S + 1023) / 1024;
+  const int b = t * per;
+  int e = b + per;
+  if (e > S) e = S;
+  auto pairs = [&](int c) { const unsigned long long m = (unsigned long long)(offsets[c + 1] - offsets[c]); return m * (m - (m ? 1 : 0)) / 2; };
+  unsigned long long sum = 0;
+  for (int i = b; i < e; ++i) sum += pairs(i);
+  part[t] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const unsigned long long v = (t >= o) ? part[t - o] : 0ull;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  unsigned long long run = (t == 0) ? 0ull : part[t - 1];
+  for (int i = b; i < e; ++i) { pair_off[i] = run; run += pairs(i); }
+  if (t == 1023) *out_count = (int64_t)part[1023];
+}
+
+// one wave per member a: its partners b > a are consecutive in `order`, so `hi` is a coalesced copy
+__global__ __launch_bounds__(256) void clique_fill_kernel(const int64_t* __restrict__ order, const int64_t* __restrict__ offsets,
+                                                          const int32_t* __restrict__ seg_of, const unsigned long long* __restrict__ pair_off,
+                                                          int64_t total, int64_t* __restrict__ lo, int64_t* __restrict__ hi, int64_t capacity) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= total) return;
+  const int c = seg_of[q];
+  const int64_t b = offsets[c], e = offsets[c + 1];
+  const unsigned long long m = (unsigned long long)(e - b), a = (unsigned long long)(q - b);
+  const unsigned long long base = pair_off[c] + a * m - a * (a + 1) / 2;      // pairs of members 0 .. a-1
+  const int64_t ra = order[q];
+  for (int64_t p = q + 1 + lane; p < e; p += 64) {
+    const unsigned long long pos = base + (unsigned long long)(p - q - 1);
+    if ((int64_t)pos < capacity) { lo[pos] = ra; hi[pos] = order[p]; }
+  }
+}
+
+size_t clique_scratch_bytes(int64_t n, int64_t S) { return ws_bytes((size_t)S + 1, 8) + ws_bytes((size_t)n, 4); }
+
+int launch_clique_pairs(const int64_t* order, const int64_t* offsets, int64_t n, int64_t S, int64_t* lo, int64_t* hi,
+                        int64_t capacity, int64_t* out_count, void* scratch, hipStream_t s) {
+  unsigned long long* pair_off = reinterpret_cast<unsigned long long*>(scratch);
+  int32_t* seg_of = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(scratch) + ws_bytes((size_t)S + 1, 8));
+  hipLaunchKernelGGL(clique_offsets_kernel, dim3(1), dim3(1024), 0, s, offsets, (int)S, pair_off, out_count);
+  MMF_LAUNCH_CHECK();
+  if (capacity > 0) {
+    hipLaunchKernelGGL(seg_of_kernel, dim3((unsigned)S), dim3(256), 0, s, offsets, (int)S, seg_of);
+    MMF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(clique_fill_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, order, offsets, seg_of, pair_off, n, lo, hi, capacity);
+    MMF_LAUNCH_CHECK();
+  }
+  return MMF_OK;
+}
+
+// ---- k-NN pairs -------------------------------------------------------------------------------------------------
+// Directed pair i -> j (j = nbr[i][t]) becomes the undirected (min, max).  It is dropped when a clique already holds it
+// (labels given and equal) or when the same pair is also emitted by the smaller row (j < i and i in nbr[j]): what is
+// left is duplicate-free without a sort.  Appended with one atomic per wave; the caller orders the union.
+__global__ __launch_bounds__(256) void knn_pairs_kernel(const int64_t* __restrict__ nbr, int64_t n, int k, const int64_t* __restrict__ labels,
+                                                        int64_t* __restrict__ lo, int64_t* __restrict__ hi,
+                                                        unsigned long long* __restrict__ count) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool keep = false;
+  int64_t i = 0, j = 0;
+  if (t < n * k) {
+    i = t / k;
+    j = nbr[t];
+    keep = (j >= 0 && j < n && j != i);
+    if (keep && labels && labels[i] == labels[j]) keep = false;
+    if (keep && j < i) {
+      for (int u = 0; u < k; ++u)
+        if (nbr[j * k + u] == i) { keep = false; break; }
+    }
+  }
+  const unsigned long long m = __ballot(keep);
+  unsigned long long base = 0;
+  if (m) {
+    if (lane == __builtin_ctzll(m)) base = atomicAdd(count, (unsigned long long)__popcll(m));
+    base = __shfl(base, __builtin_ctzll(m));
+  }
+  if (keep) {
+    const unsigned long long pos = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+    lo[pos] = i < j ? i : j;
+    hi[pos] = i < j ? j : i;
+  }
+}
+
+int launch_knn_pairs(const int64_t* nbr, int64_t n, int k, const int64_t* labels, int64_t* lo, int64_t* hi, int64_t* out_count,
+                     hipStream_t s) {
+  MMF_HIP(hipMemsetAsync(out_count, 0, 8, s));
+  const int64_t total = n * k;
+  if (total == 0) return MMF_OK;
+  hipLaunchKernelGGL(knn_pairs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, nbr, n, k, labels, lo, hi,
+                     reinterpret_cast<unsigned long long*>(out_count));
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+
+int segment_max_segments() { return SEG_MAX; }
+
+}  // namespace mmf

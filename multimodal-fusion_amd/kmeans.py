@@ -8,7 +8,8 @@ distance computations that dominate it run on the hot-path kernels of libmmf_hg.
   the centroids — labels and distances come out of one scan, the N x k matrix is never stored;
 * k-means++    = dense squared-L2 rows of the few candidate centres against all points (``mmf_sim_dense``).
 
-Centroid updates are segmented means (``index_add_``).  Bit-parity with scikit-learn is not
+Centroid updates are segmented means in a fixed summation order (``mmf_segment_sort`` + ``mmf_segment_mean``), so the
+whole fit is deterministic: same data and seed, same labels, run after run.  Bit-parity with scikit-learn is not
 achievable (its seeding consumes a Mersenne-Twister stream); parity is on the objective: same
 partition on separable data, inertia within a few per cent otherwise (tests/test_gpu_kmeans.py).
 """
@@ -69,15 +70,12 @@ def kmeans_fit_predict(X: torch.Tensor, n_clusters: int, *, n_init: int = 10, ma
         labels = None
         for _it in range(max_iter):
             labels, d2 = _assign(Xc, C)
-            counts = torch.bincount(labels, minlength=n_clusters)
-            newC = torch.zeros_like(C).index_add_(0, labels, Xc)
-            empty = counts == 0
+            seg = ops.segment_sort(labels, n_clusters)
+            newC = ops.segment_mean(Xc, seg)
+            empty = seg.counts == 0
             if bool(empty.any()):                                            # relocate empty clusters to the
                 far = torch.topk(d2, int(empty.sum())).indices               # points farthest from their centre
                 newC[empty] = Xc[far]
-                counts = counts.clone()
-                counts[empty] = 1
-            newC = newC / counts.to(newC.dtype)[:, None]
             shift = float(((newC - C) ** 2).sum())
             C = newC
             if shift <= tol_abs:

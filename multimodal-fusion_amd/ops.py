@@ -88,6 +88,33 @@ def sim_dense(X: torch.Tensor, Y: Optional[torch.Tensor] = None, *, metric="rbf"
     return out
 
 
+def _stats_dict(out: torch.Tensor) -> dict:
+    h = out.to(torch.float32).cpu().tolist()        # the reference's values are `.item()`s of f32 tensors
+    return {"mean": h[0], "std": h[1], "min": h[2], "max": h[3], "median": h[4]}
+
+
+def sim_dense_stats(X: torch.Tensor, Y: Optional[torch.Tensor] = None, *, metric="rbf_direct", lam: float = 1.0,
+                    store: bool = True, panel_rows: int = 0):
+    """(S [n, m] f32 or None, {'mean','std','min','max','median'}) from mmf_sim_dense_stats.  store=False
+    (rbf_direct only) never materialises S."""
+    X = _feat(X, "sim_dense_stats X")
+    _need_gpu(X, "sim_dense_stats")
+    if Y is not None:
+        Y = _feat(Y, "sim_dense_stats Y").to(X.dtype)
+        if Y.device != X.device or Y.shape[1] != X.shape[1]:
+            raise ValueError("sim_dense_stats: X and Y must share device and feature dim")
+    n, d = X.shape
+    m = n if Y is None else Y.shape[0]
+    if n < 1 or m < 1:
+        raise ValueError("sim_dense_stats: empty matrix")
+    out = torch.empty((n, m), dtype=torch.float32, device=X.device) if store else None
+    st = torch.empty((5,), dtype=torch.float64, device=X.device)
+    rc = _lib.lib().mmf_sim_dense_stats(_p(X), n, _p(Y), m, d, _DT[X.dtype], _metric(metric), float(lam), _p(out), _p(st),
+                                        int(panel_rows), X.device.index or 0, _stream(X.device))
+    _lib.check(rc, "mmf_sim_dense_stats")
+    return out, _stats_dict(st)
+
+
 def sim_dense_combined(F: torch.Tensor, P: torch.Tensor, lambda_h: float = 1.0, lambda_g: float = 1.0) -> torch.Tensor:
     F = _feat(F, "sim_dense_combined features").float()
     P = _feat(P, "sim_dense_combined positions").float()
@@ -143,6 +170,31 @@ def offdiag_lower_median(K: torch.Tensor) -> torch.Tensor:
     rc = _lib.lib().mmf_offdiag_lower_median(_p(K), K.shape[0], _p(out), K.device.index or 0, _stream(K.device))
     _lib.check(rc, "mmf_offdiag_lower_median")
     return out
+
+
+def lower_median(v: torch.Tensor) -> torch.Tensor:
+    """torch.median of a flat f32 tensor (lower median) by a 4-pass radix select; returns a 0-d device tensor."""
+    _need_gpu(v, "lower_median")
+    v = v.contiguous().float().reshape(-1)
+    if v.numel() < 1:
+        raise ValueError("lower_median: empty input")
+    out = torch.empty((), dtype=torch.float32, device=v.device)
+    rc = _lib.lib().mmf_lower_median(_p(v), v.numel(), _p(out), v.device.index or 0, _stream(v.device))
+    _lib.check(rc, "mmf_lower_median")
+    return out
+
+
+def array_stats(v: torch.Tensor) -> dict:
+    """{'mean','std','min','max','median'} of a dense f32 tensor as Python floats (the reference's `.item()` values:
+    f32-rounded), from one reduction pass + a radix select on the device (mmf_array_stats)."""
+    _need_gpu(v, "array_stats")
+    v = v.contiguous().float().reshape(-1)
+    if v.numel() < 1:
+        raise ValueError("array_stats: empty input")
+    out = torch.empty((5,), dtype=torch.float64, device=v.device)
+    rc = _lib.lib().mmf_array_stats(_p(v), v.numel(), _p(out), v.device.index or 0, _stream(v.device))
+    _lib.check(rc, "mmf_array_stats")
+    return _stats_dict(out)
 
 
 def threshold_edges(K: torch.Tensor, threshold: float) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -304,3 +356,85 @@ def simtopk_panels(X: torch.Tensor, Y: torch.Tensor, q: dict, c_scal: torch.Tens
     if return_stats:
         return idx, val, stats.as_dict()
     return idx, val
+
+
+# ---------------------------------------------------------------------------------------------------
+# cluster-shaped steps (mmf_segments.hip): members of each label, per-cluster means, cliques, k-NN pair dedup
+# ---------------------------------------------------------------------------------------------------
+class Segments:
+    """Members of every label, grouped: `order[offsets[c]:offsets[c+1]]` are the rows of segment c, ascending."""
+    __slots__ = ("counts", "offsets", "order", "n", "n_segments")
+
+    def __init__(self, counts, offsets, order, n, n_segments):
+        self.counts, self.offsets, self.order, self.n, self.n_segments = counts, offsets, order, n, n_segments
+
+
+def segment_sort(labels: torch.Tensor, n_segments: int) -> Segments:
+    """Stable counting sort of integer labels in [0, n_segments) on the device (mmf_segment_sort)."""
+    _need_gpu(labels, "segment_sort")
+    lab = labels.to(torch.int64).contiguous().reshape(-1)
+    n, S = lab.numel(), int(n_segments)
+    counts = torch.empty((S,), dtype=torch.int64, device=lab.device)
+    offsets = torch.empty((S + 1,), dtype=torch.int64, device=lab.device)
+    order = torch.empty((n,), dtype=torch.int64, device=lab.device)
+    rc = _lib.lib().mmf_segment_sort(_p(lab), n, S, _p(counts), _p(offsets), _p(order), lab.device.index or 0,
+                                     _stream(lab.device))
+    _lib.check(rc, "mmf_segment_sort")
+    return Segments(counts, offsets, order, n, S)
+
+
+def segment_mean(X: torch.Tensor, seg: Segments) -> torch.Tensor:
+    """[n_segments, d] per-segment mean of the rows of X (f32), summed in member order (mmf_segment_mean)."""
+    X = _feat(X, "segment_mean X").float()
+    _need_gpu(X, "segment_mean")
+    if X.shape[0] != seg.n:
+        raise ValueError("segment_mean: X has a different number of rows than the labels")
+    out = torch.empty((seg.n_segments, X.shape[1]), dtype=torch.float32, device=X.device)
+    rc = _lib.lib().mmf_segment_mean(_p(X), X.shape[0], X.shape[1], _p(seg.order), _p(seg.offsets), seg.n_segments,
+                                     _p(out), X.device.index or 0, _stream(X.device))
+    _lib.check(rc, "mmf_segment_mean")
+    return out
+
+
+def segment_offdiag_mean(K: torch.Tensor, seg: Segments) -> torch.Tensor:
+    """[n_segments] f64: mean of K[i, j] over the ordered pairs i != j inside each segment (NaN below two members)."""
+    _need_gpu(K, "segment_offdiag_mean")
+    K = K.contiguous().float()
+    if K.dim() != 2 or K.shape[0] != K.shape[1] or K.shape[0] != seg.n:
+        raise ValueError("segment_offdiag_mean: K must be [n, n] with n = number of labels")
+    out = torch.empty((seg.n_segments,), dtype=torch.float64, device=K.device)
+    rc = _lib.lib().mmf_segment_offdiag_mean(_p(K), K.shape[0], _p(seg.order), _p(seg.offsets), seg.n_segments, _p(out),
+                                             K.device.index or 0, _stream(K.device))
+    _lib.check(rc, "mmf_segment_offdiag_mean")
+    return out
+
+
+def clique_pairs(seg: Segments) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(lo, hi) int64: every pair a < b inside every segment (mmf_clique_pairs: count, then fill)."""
+    dev = seg.order.device
+    cnt = torch.zeros((), dtype=torch.int64, device=dev)
+    L = _lib.lib()
+    args = (_p(seg.order), _p(seg.offsets), seg.n, seg.n_segments)
+    _lib.check(L.mmf_clique_pairs(*args, None, None, 0, _p(cnt), dev.index or 0, _stream(dev)), "mmf_clique_pairs")
+    E = int(cnt.item())
+    lo = torch.empty((E,), dtype=torch.int64, device=dev)
+    hi = torch.empty((E,), dtype=torch.int64, device=dev)
+    if E:
+        _lib.check(L.mmf_clique_pairs(*args, _p(lo), _p(hi), E, _p(cnt), dev.index or 0, _stream(dev)), "mmf_clique_pairs")
+    return lo, hi
+
+
+def knn_pairs(nbr: torch.Tensor, labels: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Undirected duplicate-free (lo, hi) pairs of a [n, k] neighbour table; pairs inside one label are left to the
+    cliques (mmf_knn_pairs).  Order unspecified."""
+    _need_gpu(nbr, "knn_pairs")
+    nbr = nbr.to(torch.int64).contiguous()
+    n, k = nbr.shape
+    lab = None if labels is None else labels.to(device=nbr.device, dtype=torch.int64).contiguous()
+    lo = torch.empty((n * k,), dtype=torch.int64, device=nbr.device)
+    hi = torch.empty((n * k,), dtype=torch.int64, device=nbr.device)
+    cnt = torch.zeros((), dtype=torch.int64, device=nbr.device)
+    rc = _lib.lib().mmf_knn_pairs(_p(nbr), n, k, _p(lab), _p(lo), _p(hi), _p(cnt), nbr.device.index or 0, _stream(nbr.device))
+    _lib.check(rc, "mmf_knn_pairs")
+    E = int(cnt.item())
+    return lo[:E], hi[:E]

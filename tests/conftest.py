@@ -31,3 +31,16 @@ def unit_rows(n, d, seed):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, d, generator=g, dtype=torch.float32)
     return x / x.norm(dim=1, keepdim=True)
+
+
+@pytest.fixture()
+def sklearn_kmeans():
+    """Run the mirrors' KMeans steps through the reference's own scikit-learn call, so labels — and the edges built on
+    them — can be compared with the fixtures the reference produced.  (The default backend is the device KMeans.)"""
+    from importlib import import_module
+    import multimodal_fusion_amd  # noqa: F401
+    pp = import_module("multimodal_fusion_amd.build_hypergraph.preprocess_hypergraph")
+    prev = pp.KMEANS_BACKEND
+    pp.set_kmeans_backend("sklearn")
+    yield pp
+    pp.set_kmeans_backend(prev)

@@ -49,6 +49,8 @@ def test_abi_has_no_cpu_path():
 def test_mirror_signatures_match_the_reference():
     sigs = json.load(open(os.path.join(ROOT, "tests", "golden", "signatures.json")))
     for pkg, fns in sigs.items():
+        if pkg.endswith("__all__"):
+            continue
         mod = import_module("multimodal_fusion_amd." + pkg)
         for name, params in fns.items():
             fn = getattr(mod, name, None) or getattr(import_module("multimodal_fusion_amd." + pkg + ".similarity_kernel"), name)
@@ -59,6 +61,10 @@ def test_mirror_signatures_match_the_reference():
 
 def test_reference_exports_present():
     b = import_module("multimodal_fusion_amd.build_hypergraph")
+    sigs = json.load(open(os.path.join(ROOT, "tests", "golden", "signatures.json")))
+    assert list(b.__all__) == sigs["build_hypergraph.__all__"] and len(b.__all__) == 17      # build_hypergraph/__init__.py:28-46
+    for n in b.__all__:
+        assert callable(getattr(b, n)), n
     h = import_module("multimodal_fusion_amd.hypergraph.build_hypergraph")
     for n in ("compute_morphological_similarity", "compute_spatial_similarity", "compute_combined_similarity",
               "build_weighted_hypergraph", "mean_pool_with_similarity"):

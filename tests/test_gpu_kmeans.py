@@ -46,11 +46,15 @@ def test_mirror_with_device_kmeans_backend():
     rng = np.random.RandomState(2)
     centers = rng.randn(4, 16).astype(np.float32) * 5.0
     X = torch.from_numpy(np.concatenate([c + rng.randn(50, 16).astype(np.float32) for c in centers], 0))
+    prev = pp.KMEANS_BACKEND
     try:
+        pp.set_kmeans_backend("sklearn")
         ei_s, ew_s, st_s = pp.build_hypergraph_knn_kmeans(X[:120], X[120:], None, 5, 4)
         pp.set_kmeans_backend("device")
         ei_d, ew_d, st_d = pp.build_hypergraph_knn_kmeans(X[:120], X[120:], None, 5, 4)
+        ei_d2, ew_d2, _ = pp.build_hypergraph_knn_kmeans(X[:120], X[120:], None, 5, 4)
+        assert torch.equal(ei_d, ei_d2) and torch.equal(ew_d, ew_d2)          # the device KMeans is deterministic
     finally:
-        pp.set_kmeans_backend("sklearn")
+        pp.set_kmeans_backend(prev)
     # separable blobs: both backends find the same 4 cliques, hence the same edge set and weights
     assert torch.equal(ei_s, ei_d) and torch.equal(ew_s, ew_d) and st_s == st_d
