@@ -1,27 +1,35 @@
-// mmf_scan_bf16.hip — the fast all-pairs scan: bf16 / f16 MFMA candidate generation with a proven
+// mmf_scan_bf16.hip — the fast all-pairs scan: f16 / bf16 MFMA candidate generation with a proven
 // error margin; the exact f32 re-rank (mmf_select.hip) turns the candidates into the final rows.
 //
 // Shape of the work: like a flash-attention S = Q K^T pass with head dim d and no
-// softmax/PV.  A workgroup = 8 waves owns 256 queries for its whole column range:
+// softmax/PV.  A workgroup = 8 waves owns 256 queries for its whole column range (4 waves / 128 queries for d > 512):
 //   * each wave keeps its 32 queries RESIDENT IN REGISTERS as the MFMA B operand
-//     (KS x bf16x8 = 128 VGPRs at d = 512), loaded once;
-//   * candidate tiles of 32 rows x d stream HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, one
-//     1 KiB piece per wave instruction), 3 stages, ONE s_barrier per tile, counted vmcnt;
+//     (KS x 8 halves = 128 VGPRs at d = 512), loaded once;
+//   * candidate tiles of 32 rows x d stream L2/HBM -> LDS by buffer-form LDS-DMA (one 1 KiB piece per wave
+//     instruction, scalar tile offset) into a 4-stage ring used as two pairs: an iteration reads one pair — TWO
+//     tiles per s_barrier — while the pieces of the next pair are issued inside the MFMA chains; at the top of an
+//     iteration a wave's outstanding DMA is exactly what the iteration needs (vmcnt(0), barrier);
 //   * the LDS image is the candidates' natural row-major layout with the 16-byte chunk index XORed
 //     by (row & 15) — applied on the DMA *source* address, LDS stays lane-linear — so every
 //     ds_read_b128 of an A fragment is bank-conflict free;
-//   * v_mfma_f32_32x32x16_{bf16,f16}: C rows = candidates, C columns = queries, so a lane holds ONE
-//     query and 16 candidates per tile; the accumulator is initialised with the per-candidate bias
-//     (-n_j/2 for the L2 metrics, -inf for padding) instead of zero, which costs nothing;
-//   * epilogue per tile: 8 v_max3 + 1 compare; only a hit enters the lane-private list code.
+//   * v_mfma_f32_16x16x32_{f16,bf16}, 2 x 2 tiles per wave (32 candidates x 32 queries), four independent
+//     accumulator chains: C rows = candidates, C columns = queries, a lane holds TWO queries x 8 candidates per tile;
+//     the accumulators are initialised with the per-candidate bias (-n_j/2 for the L2 metrics, -inf for padding)
+//     instead of zero, which costs nothing;
+//   * epilogue per tile: 14 v_max + 2 compares, reduced before the barrier, tested behind it; only a hit enters
+//     the lane-private list code (SlotList, mmf_dev.h).
+// Where the time goes (profiles/README.md, r02 ablations): the bare ds_read + MFMA chain alone runs at 0.60 of the
+// 2.5 PFLOP/s peak (matrix pipe 73 % busy at the 1.94 GHz the chip holds under this load); the tile DMA adds 6 %
+// (instruction issue, not traffic), the list code 10 %.
 //
-// Error margin: with u the f32 rows (normalised for cosine), z = round_bf16(u), the scanned value
+// Error margin: with u the f32 rows (normalised for cosine), z = round_16(u), the scanned value
 // G = bias_j + z_i.z_j differs from the real-number target Q = bias_j + u_i.u_j by at most
 //   E1_i = |dz_i| max|z_j| + |u_i| max|dz_j| + (DP+8) 2^-24 (|z_i| max|z_j| + max|bias|)
 // and the canonical f32 key (mapped to Q units) differs from Q by at most E2_i (rounding of the
 // chain and of the metric's few f32 ops).  Every column that can be in the canonical top-k has
 // G >= (k-th best G) - 2(E1+E2); the lists keep exactly those, so the re-rank sees a superset.
-// A list that cannot hold them (too many near-ties) flags the row; it is rescanned by the exact kernel.
+// A list that cannot hold them hands the surplus to the row's overflow list; a row that fills that too is flagged
+// and rescanned by the exact kernel.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -195,7 +203,9 @@ struct ScanB16Args {
   int kk;
   int metric;
   int d;
-  int debug;                 // MMF_SCAN_DEBUG: 1 = skip the filter / list code (timing only), 8 = count events
+  int debug;                 // MMF_SCAN_DEBUG (instrumented build of the same template; scripts/ablate.py): 1 = skip the filter /
+                             // list code, 2 = no tile DMA, 4 = no barrier, 32 = DMA of tile 0 only (1, 2, 4, 32: timing only, the
+                             // results are wrong), 8 = count events, 16 = cycle stamps, 64 = instrumented build, nothing removed
   unsigned long long* dbg;   // [8] event counters when debug & 8
   uint32_t* lids;            // lane-private id slots: [grid][16][B_NT] (global, written on push, read once at the end)
   uint32_t* cand_cnt; uint32_t* cand_ids; uint32_t* overflow;
@@ -368,6 +378,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
   // global form) it leaves the compiler's counted lgkmcnt waits for the A-fragment ring intact.
   const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(zc0), 0, -1, 0x00020000);
   auto issue_piece = [&](const char* tsrc, int stage, int i) {
+    if (DBG && (a.debug & 2)) return;       // timing-only ablation: no tile DMA (the chain runs on whatever LDS holds)
+    if (DBG && (a.debug & 32)) tsrc = zc0;  // timing-only ablation: every piece re-fetches tile 0 (issue cost without the traffic)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(zrsrc, (__attribute__((address_space(3))) void*)(tiles + stage * TILEB + (wave + NW * i) * 1024),
                                              16, (int)src_off[i], (int)(uint32_t)(tsrc - zc0), 0, 0);
   };
@@ -515,7 +527,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
   // and fills the other group with the next TPB tiles (DMA pieces issued inside the MFMA chains), so at
   // the top of an iteration everything this wave has in flight is exactly what the iteration needs:
   // vmcnt(0), barrier.  Past the end of the range the DMA re-fetches tile 0 into a stage nobody reads.
-  unsigned long long tw = 0, tf = 0, tc = 0, t0s = 0, t1s = 0, t2s = 0, t3s = 0;
+  unsigned long long tw = 0, tf = 0, tc = 0, tv = 0, t0s = 0, t1s = 0, t2s = 0, t3s = 0, tvs = 0;
   const bool stamps = DBG && (a.debug & 16) != 0;
   Acc acc_prev;
   float m0_prev = kNegInf, m1_prev = kNegInf;
@@ -526,9 +538,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
   }
   const int nIter = (Ti + TPB - 1) / TPB;
   for (int j = 0; j < nIter; ++j) {
+    if (stamps) tvs = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) alone (expcnt 7, lgkmcnt 15 = no wait)
     if (stamps) t0s = __builtin_amdgcn_s_memtime();
     asm volatile("" ::: "memory");
+    if (!(DBG && (a.debug & 4)))    // timing-only ablation: no workgroup barrier (races)
     __builtin_amdgcn_s_barrier();   // this group is visible to all; everyone is done READING the other group
     asm volatile("" ::: "memory");
     if (stamps) t1s = __builtin_amdgcn_s_memtime();
@@ -565,11 +579,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
     if (stamps) {
       asm volatile("" :: "v"(acc_prev.t[0][0][0]));  // the chain's result must exist before the stamp
       t3s = __builtin_amdgcn_s_memtime();
-      tw += t1s - t0s; tf += t2s - t1s; tc += t3s - t2s;
+      tw += t1s - t0s; tf += t2s - t1s; tc += t3s - t2s; tv += t0s - tvs;
     }
   }
   if (stamps && lane == 0) {
     atomicAdd(a.dbg + 0, tw); atomicAdd(a.dbg + 1, tf); atomicAdd(a.dbg + 2, tc); atomicAdd(a.dbg + 3, (unsigned long long)Ti);
+    atomicAdd(a.dbg + 8, tv);
   }
   if (Ti > 0) filter(acc_prev, nIter * TPB - 1, max_qb(acc_prev, 0), max_qb(acc_prev, 1));
   __builtin_amdgcn_s_waitcnt(0x0F70);   // the dummy tiles still in flight
@@ -713,8 +728,8 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
     a.dbg = nullptr;
     if (a.debug & (8 | 16)) {
       static unsigned long long* dbuf = nullptr;
-      if (!dbuf) MMF_HIP(hipMalloc(&dbuf, 64));
-      MMF_HIP(hipMemsetAsync(dbuf, 0, 64, s));
+      if (!dbuf) MMF_HIP(hipMalloc(&dbuf, 128));
+      MMF_HIP(hipMemsetAsync(dbuf, 0, 128, s));
       a.dbg = dbuf;
     }
   }
@@ -724,7 +739,7 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
   a.lids = reinterpret_cast<uint32_t*>(scratch);
   if (grid_out) *grid_out = (int)grid;
   int rc = MMF_E_INTERNAL;
-  const bool big = (L.cap == B_CAP_BIG);   // k + self in 9..12: 16-entry lists, one tile per barrier
+  const bool big = (L.cap == B_CAP_BIG);   // k + self in 12..20: 16-entry lists, one tile per barrier
   switch (dp) {
     case 128: rc = big ? launch_b16_t<8, 8, 1, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<8, 8, 2, B_CAP>(a, f16, grid, s); break;
     case 256: rc = big ? launch_b16_t<16, 8, 1, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<16, 8, 2, B_CAP>(a, f16, grid, s); break;
@@ -733,12 +748,12 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
     default: set_error("scan_b16: unsupported padded dim %d", dp);
   }
   if (rc == MMF_OK && (a.debug & 16)) {
-    unsigned long long h[8];
-    MMF_HIP(hipMemcpyAsync(h, a.dbg, 64, hipMemcpyDeviceToHost, s));
+    unsigned long long h[16];
+    MMF_HIP(hipMemcpyAsync(h, a.dbg, 128, hipMemcpyDeviceToHost, s));
     MMF_HIP(hipStreamSynchronize(s));
     const double tiles = (double)h[3];
-    fprintf(stderr, "[mmf scan stamps] per wave-tile cycles: barrier-wait %.0f  filter %.0f  chain(+DMA issue) %.0f  (sum %.0f)\n",
-            h[0] / tiles, h[1] / tiles, h[2] / tiles, (h[0] + h[1] + h[2]) / tiles);
+    fprintf(stderr, "[mmf scan stamps] per wave-tile cycles: dma-wait %.0f  barrier-wait %.0f  filter %.0f  chain(+DMA issue) %.0f  (sum %.0f)\n",
+            h[8] / tiles, h[0] / tiles, h[1] / tiles, h[2] / tiles, (h[8] + h[0] + h[1] + h[2]) / tiles);
     fprintf(stderr, "[mmf scan stamps] list code: cold entries %llu x %.0f cycles, warm entries %llu x %.0f cycles\n",
             h[6], h[6] ? (double)h[4] / h[6] : 0.0, h[7], h[7] ? (double)h[5] / h[7] : 0.0);
   }
