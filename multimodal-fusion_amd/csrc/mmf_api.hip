@@ -447,7 +447,7 @@ int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d
     return MMF_E_UNSUPPORTED;
   }
   const int cap = scan_f32_cap(kk);
-  if (cap == 0) { set_error("simtopk: k = %d is above the supported maximum (27 with self excluded, 28 without)", k); return MMF_E_UNSUPPORTED; }
+  if (cap == 0) { set_error("simtopk: k = %d is above the supported maximum (43 with self excluded, 44 without)", k); return MMF_E_UNSUPPORTED; }
 
   if (precision != MMF_PREC_EXACT) {
     // ---- fast path: f16/bf16 MFMA scan -> exact re-rank -> exact rescan of overflowed rows -------

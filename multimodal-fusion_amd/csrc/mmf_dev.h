@@ -287,13 +287,13 @@ struct LaneList {
     cnt = w;
   }
 
-  // CAP > 16 (large k, rare): ranks by counting straight out of LDS; the partner's list is read in
+  // CAP > 16 (large k, rare; CAP <= 64): ranks by counting straight out of LDS; the partner's list is read in
   // place (same wave, so its LDS writes are already ordered before these reads).
   template <bool EXACT>
   __device__ __forceinline__ void compact_ranked(int kk, float margin) {
     const int pofs = (int)((threadIdx.x ^ 32u) - threadIdx.x);
     const int pcnt = __shfl_xor(cnt, 32);
-    uint32_t topmask = 0;
+    unsigned long long topmask = 0;
     float t_own = kNegInf;
     for (int e = 0; e < cnt; ++e) {
       const float ke = keys[e * NT];
@@ -302,7 +302,7 @@ struct LaneList {
       for (int f = 0; f < cnt; ++f) r_own += better(keys[f * NT], ids[f * NT], ke, ie) ? 1 : 0;
       for (int f = 0; f < pcnt; ++f) r_par += better(keys[f * NT + pofs], ids[f * NT + pofs], ke, ie) ? 1 : 0;
       if (r_own + r_par == kk - 1) t_own = ke;
-      if (r_own < kk) topmask |= 1u << e;
+      if (r_own < kk) topmask |= 1ull << e;
     }
     const float t = fmaxf(t_own, __shfl_xor(t_own, 32));
     raise_thr(t, margin, EXACT);
@@ -310,7 +310,7 @@ struct LaneList {
     for (int e = 0; e < cnt; ++e) {
       const float ke = keys[e * NT];
       const uint32_t ie = ids[e * NT];
-      const bool kp = (ke >= thr) && (!EXACT || ((topmask >> e) & 1u));
+      const bool kp = (ke >= thr) && (!EXACT || ((topmask >> e) & 1ull));
       if (kp) {
         keys[w * NT] = ke;
         ids[w * NT] = ie;

@@ -315,6 +315,7 @@ __global__ __launch_bounds__(F_NT, (MODE == MODE_DENSE || CAP <= 16) ? 2 : 1) vo
 int scan_f32_cap(int kk) {
   if (kk <= 12) return 16;
   if (kk <= 28) return 32;
+  if (kk <= 44) return 48;     // 48 x 256 x 8 B of lists + 36 KB of tiles: one workgroup per CU
   return 0;
 }
 
@@ -361,6 +362,7 @@ int launch_scan_f32(const ScanProblem& p, const CandLists& L, hipStream_t s, int
   { const char* e = getenv("MMF_F32_DEBUG"); a.debug = e ? atoi(e) : 0; }
   if (L.cap == 16) return launch_f32_t<MODE_SCAN, 16>(a, v4, grid, s);
   if (L.cap == 32) return launch_f32_t<MODE_SCAN, 32>(a, v4, grid, s);
+  if (L.cap == 48) return launch_f32_t<MODE_SCAN, 48>(a, v4, grid, s);
   set_error("scan_f32: unsupported list capacity %d", L.cap);
   return MMF_E_INTERNAL;
 }

@@ -71,6 +71,23 @@ def test_simtopk_self_exact(mmf, metric, n, d, k):
     check_topk(mmf, X, None, metric, k, lam=1.0)
 
 
+@pytest.mark.parametrize("metric", ["cosine", "neg_sq_l2"])
+@pytest.mark.parametrize("n,d,k,exclude", [(400, 64, 28, True), (400, 64, 32, True), (3000, 128, 32, True), (3000, 128, 43, True),
+                                           (700, 96, 44, False), (5000, 256, 33, True)])
+def test_simtopk_large_k_on_the_exact_scan(mmf, metric, n, d, k, exclude):
+    """sklearn's NearestNeighbors has no cap on n_neighbors (preprocess_hypergraph.py:379); the exact scan's 48-entry
+    lists carry k + self up to 44, AUTO routes there beyond what the 16-bit scan's lists hold."""
+    X = unit_rows(n, d, 100 + n + k).numpy()
+    if exclude:
+        check_topk(mmf, X, None, metric, k, precision="exact")
+        check_topk(mmf, X, None, metric, k, precision="auto")
+    else:
+        Y = unit_rows(n + 50, d, 7).numpy()
+        check_topk(mmf, X, Y, metric, k, precision="auto")
+    with pytest.raises(RuntimeError, match="supported maximum"):
+        mmf.simtopk(dev(X), metric=metric, k=45)
+
+
 # the bf16 MFMA scan + exact re-rank must give the SAME bits as the exact scan and the oracle
 @pytest.mark.parametrize("metric", ["dot", "cosine", "neg_sq_l2", "rbf"])
 @pytest.mark.parametrize("n,d,k", [(2, 4, 1), (33, 3, 5), (300, 32, 5), (1000, 128, 7), (257, 100, 7), (2049, 512, 5),
