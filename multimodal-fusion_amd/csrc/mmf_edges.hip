@@ -258,8 +258,16 @@ __global__ __launch_bounds__(256) void thr_count_kernel(const float* __restrict_
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  const float* kr = K + row * n;
   uint32_t c = 0;
-  for (int64_t j = lane; j < n; j += 64) c += (K[row * n + j] < thr) ? 0u : 1u;  // skipped iff K < thr (:198)
+  if (((n & 3) == 0) && ((reinterpret_cast<uintptr_t>(K) & 15) == 0)) {       // 16 bytes per lane, 1 KiB per wave instruction
+    for (int64_t j = (int64_t)lane * 4; j < n; j += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(kr + j);
+      c += (v[0] < thr ? 0u : 1u) + (v[1] < thr ? 0u : 1u) + (v[2] < thr ? 0u : 1u) + (v[3] < thr ? 0u : 1u);   // skipped iff K < thr (:198)
+    }
+  } else {
+    for (int64_t j = lane; j < n; j += 64) c += (kr[j] < thr) ? 0u : 1u;
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor((int)c, o);
   if (lane == 0) row_cnt[row] = c;
@@ -300,10 +308,29 @@ __global__ __launch_bounds__(256) void thr_fill_kernel(const float* __restrict__
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  const float* kr = K + row * n;
   unsigned long long pos = row_off[row];
-  for (int64_t j0 = 0; j0 < n; j0 += 64) {
+  // Four 64-column groups per trip: the four loads are in flight together, and every store instruction writes the
+  // kept entries of one group to CONSECUTIVE positions (a lane-owns-4-columns layout would make the stores strided).
+  int64_t j0 = 0;
+  for (; j0 + 256 <= n; j0 += 256) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = kr[j0 + 64 * u + lane];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool keep = !(v[u] < thr);
+      const unsigned long long mask = __ballot(keep);
+      if (keep) {
+        const unsigned long long p = pos + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+        if ((int64_t)p < capacity) { ei_row[p] = row0 + row; ei_col[p] = j0 + 64 * u + lane; ew[p] = v[u]; }
+      }
+      pos += (unsigned long long)__popcll(mask);
+    }
+  }
+  for (; j0 < n; j0 += 64) {
     const int64_t j = j0 + lane;
-    const float v = (j < n) ? K[row * n + j] : 0.0f;
+    const float v = (j < n) ? kr[j] : 0.0f;
     const bool keep = (j < n) && !(v < thr);
     const unsigned long long mask = __ballot(keep);
     if (keep) {

@@ -12,7 +12,9 @@
 // chunks of 32 (double buffered, one barrier per chunk).  Wave w owns queries 32w..32w+31 as the MFMA
 // column (B operand) and sweeps the 4 candidate sub-tiles as MFMA rows (A operand), so every lane
 // keeps ONE query and its candidate list is lane-private (mmf_dev.h).
-// LDS rows are padded to 33 floats: lanes 0..31 of a ds_read_b32 hit 32 distinct banks.
+// LDS rows are padded to KC + 1 floats: lanes 0..31 of a ds_read_b32 hit 32 distinct banks.  (An 8-byte image —
+// k0 k2 | k1 k3 inside every group of four, one ds_read_b64 per operand per two k-steps, ds_write_b64 staging —
+// halves the LDS instructions and measured 6 % SLOWER in a same-process A/B, round 2: the 4-byte image stays.)
 //
 // Replaces: torch.mm + 3 elementwise passes, build_hypergraph/similarity_kernel.py:43-52, 79-84, 122;
 //           sklearn brute-force kneighbors, build_hypergraph/preprocess_hypergraph.py:379-382.

@@ -130,28 +130,40 @@ int launch_segment_sort(const int64_t* labels, int64_t n, int64_t S, int64_t* co
 }
 
 // ---- per-cluster mean of rows -----------------------------------------------------------------------------------
-// Workgroup = (cluster, strip of 64 columns); wave w adds the cluster's rows w, w + 4, ... in member order, the four
-// partial sums are combined in wave order: one fixed summation order, coalesced 256-byte row segments.
-__global__ __launch_bounds__(256) void seg_mean_kernel(const float* __restrict__ X, int64_t d, const int64_t* __restrict__ order,
-                                                       const int64_t* __restrict__ offsets, float* __restrict__ out) {
-  __shared__ float part[4][64];
+// Workgroup = (cluster, strip of 64 columns), 8 waves; wave w adds the cluster's rows w, w + 8, ... in member order
+// (four row loads in flight, added in order), the eight partial sums are combined in wave order: one fixed summation
+// order, coalesced 256-byte row segments.
+constexpr int SM_W = 8;
+__global__ __launch_bounds__(64 * SM_W) void seg_mean_kernel(const float* __restrict__ X, int64_t d, const int64_t* __restrict__ order,
+                                                             const int64_t* __restrict__ offsets, float* __restrict__ out) {
+  __shared__ float part[SM_W][64];
   const int c = blockIdx.x;
-  const int64_t col = (int64_t)blockIdx.y * 64 + (threadIdx.x & 63);
+  const int lane = threadIdx.x & 63;
+  const int64_t col = (int64_t)blockIdx.y * 64 + lane;
   const int w = threadIdx.x >> 6;
   const int64_t b = offsets[c], e = offsets[c + 1];
   float acc = 0.f;
-  if (col < d)
-    for (int64_t q = b + w; q < e; q += 4) acc += X[order[q] * d + col];
-  part[w][threadIdx.x & 63] = acc;
+  if (col < d) {
+    int64_t q = b + w;
+    for (; q + 3 * SM_W < e; q += 4 * SM_W) {
+      const int64_t r0 = order[q], r1 = order[q + SM_W], r2 = order[q + 2 * SM_W], r3 = order[q + 3 * SM_W];
+      const float x0 = X[r0 * d + col], x1 = X[r1 * d + col], x2 = X[r2 * d + col], x3 = X[r3 * d + col];
+      acc += x0; acc += x1; acc += x2; acc += x3;
+    }
+    for (; q < e; q += SM_W) acc += X[order[q] * d + col];
+  }
+  part[w][lane] = acc;
   __syncthreads();
   if (w == 0 && col < d) {
-    const float sum = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+    float sum = part[0][lane];
+#pragma unroll
+    for (int i = 1; i < SM_W; ++i) sum += part[i][lane];
     out[(int64_t)c * d + col] = sum / (float)(e - b);            // empty cluster: 0 / 0 = NaN (the caller rejects it first)
   }
 }
 
 int launch_segment_mean(const float* X, int64_t d, const int64_t* order, const int64_t* offsets, int64_t S, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(seg_mean_kernel, dim3((unsigned)S, (unsigned)((d + 63) / 64)), dim3(256), 0, s, X, d, order, offsets, out);
+  hipLaunchKernelGGL(seg_mean_kernel, dim3((unsigned)S, (unsigned)((d + 63) / 64)), dim3(64 * SM_W), 0, s, X, d, order, offsets, out);
   MMF_LAUNCH_CHECK();
   return MMF_OK;
 }
