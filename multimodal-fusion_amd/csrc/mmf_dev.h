@@ -468,12 +468,22 @@ struct SlotList {
 #pragma unroll
     for (int e = 0; e < CAP; ++e) keep += ((e < cnt) && (k[e] >= thr)) ? 1 : 0;
     float cut = thr;
-    if (keep >= CAP - 1) cut = k[CAP - 3];   // crowded: only the CAP-2 best stay in the list
+    int room = CAP - 2;
+    if (keep >= CAP - 1) {
+      // crowded (near-duplicate columns: more of them inside the band than the list holds).  With an overflow list and
+      // kk <= CAP / 2 - 1 only this lane's CAP / 2 + 1 best stay — more than the threshold (k-th best of the two
+      // partner lists) can ever need of it — so the list does not fill up again at the very next hit; keeping CAP - 2
+      // made every slow-path entry of a crowded wave a compaction.  The rest of the band moves to the overflow list.
+      constexpr int SMALL = CAP / 2 + 1;
+      const bool deep = sink.cap != 0 && kk + 2 <= SMALL;
+      cut = deep ? k[SMALL - 1] : k[CAP - 3];
+      room = deep ? SMALL : CAP - 2;
+    }
     int w = 0;
     uint32_t nused = 0;
     for (int e = 0; e < cnt; ++e) {     // in-place filter of the LDS keys, lane-private
       const float ke = keys[e * NT];
-      if (ke >= cut && w < CAP - 2) {
+      if (ke >= cut && w < room) {
         keys[w * NT] = ke; nused |= 1u << (__float_as_uint(ke) & 15u); ++w;
       } else if (ke >= thr) {           // still inside the band: to the overflow list, else lost (audited)
         if (!sink.put(idslot[(__float_as_uint(ke) & 15u) * NT])) lost = fmaxf(lost, ke);
