@@ -236,11 +236,19 @@ __device__ __forceinline__ void glds4(const void* gptr, const void* lptr) {
 // on the (rare) slow path the lanes l and l ^ 16 swap the 8 values they hold for each other's query.
 // NW waves per workgroup (32 queries each), TPB tiles per barrier (2 * TPB tile stages in LDS):
 //   d <= 512 : NW = 8 (two waves per SIMD, 256 VGPRs each), TPB = 2
-//   d <= 1024: NW = 4 (one wave per SIMD, the 256 VGPRs of resident query fragments spill over into AGPRs), TPB = 1
-template <int KS, bool F16, bool DBG, int NW, int TPB, int CAP>
+//   d <= 1024: SPLITK — NW = 8, TPB = 1: the waves w and w + 4 share 32 queries and a SIMD; each keeps HALF of every
+//              query's k range resident (128 VGPRs), walks that half of every tile, and the upper-half wave hands its
+//              partial accumulators to the lower-half wave through LDS (one 16 KiB exchange block, acknowledged per
+//              tile), which adds them behind the next barrier and runs the filter / lists.  Two waves per SIMD hide
+//              each other's DMA issue, as at d <= 512.
+//              (k + self in 12..20 at d <= 1024: NW = 4, one wave per SIMD with all of k — its 16-entry lists leave no
+//              room for the exchange block.)
+template <int KS, bool F16, bool DBG, int NW, int TPB, int CAP, bool SPLITK = false>
 __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(ScanB16Args a) {
-  constexpr int NT = 64 * NW;
-  constexpr int QT = 32 * NW;
+  static_assert(!SPLITK || (TPB == 1 && NW == 8 && (KS % 8) == 0), "split-k pairs");
+  constexpr int NQW = SPLITK ? NW / 2 : NW;     // waves that own queries and lists
+  constexpr int NTL = 64 * NQW;                 // threads that own lists
+  constexpr int QT = 32 * NQW;
   constexpr int STAGES = 2 * TPB;
   constexpr int ROWB = KS * 32;                 // bytes per candidate row in LDS (= DP * 2)
   constexpr int TILEB = B_CT * ROWB;            // bytes per tile
@@ -252,12 +260,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
   float* cbs = reinterpret_cast<float*>(smem + STAGES * TILEB);      // [STAGES][64]
   // Candidate lists (SlotList, mmf_dev.h): approximate keys in LDS, column ids in a global slot block of
   // this workgroup — leaving most of LDS to the tile ring is what buys the fourth stage.
-  float* lkeys = cbs + STAGES * 64;                                  // [CAP][NT]
-  uint32_t* lids = a.lids + (size_t)blockIdx.x * (16 * NT);
+  float* lkeys = cbs + STAGES * 64;                                  // [CAP][NTL]
+  uint32_t* lids = a.lids + (size_t)blockIdx.x * (16 * NTL);
+  f32x4* xch = reinterpret_cast<f32x4*>(lkeys + CAP * NTL);          // SPLITK: [NQW][4][64] partial accumulators
+  volatile int* ack = reinterpret_cast<volatile int*>(xch + NQW * 4 * 64);   // SPLITK: [NQW] last tile the lower wave took
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int khalf = SPLITK ? wave / NQW : 0;    // which half of k this wave multiplies
+  const int qw = SPLITK ? wave % NQW : wave;    // which 32 queries
+  const bool owner = khalf == 0;                // bias, filter and lists live in the lower-half wave
   const int half = lane >> 5;
   const int g = lane >> 4;                      // row group of the C layout: rows 4 g .. 4 g + 3 of each 16-row tile
   const int c16 = lane & 15;
@@ -287,8 +300,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
   if (t_begin > t_end) t_begin = t_end;
   const int64_t T = t_end - t_begin;
 
-  const int64_t qpos = q0 + 32 * wave + c;
-  const bool qvalid = qpos < a.n_rows;
+  const int64_t qpos = q0 + 32 * qw + c;
+  const bool qvalid = (qpos < a.n_rows) && owner;
 
   // margin of this lane's query (see the header): 2 (E1 + E2)
   float margin;
@@ -307,8 +320,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
     margin = 2.0f * (e1 + e2) * 1.001f + 1e-30f;
   }
 
-  SlotList<CAP, NT> list;
-  list.init(lkeys + tid, lids + tid);
+  SlotList<CAP, NTL> list;
+  list.init(lkeys + (tid & (NTL - 1)), lids + (tid & (NTL - 1)));
   if (!qvalid) list.thr = __builtin_huge_valf();
   else if (a.spill_cnt) {
     list.sink.cnt = a.spill_cnt; list.sink.ids = a.spill_ids; list.sink.cap = (uint32_t)a.spill_cap; list.sink.row = qpos;
@@ -338,10 +351,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
 
   // resident query fragments: B operand of k-step s (32 wide), query block qb: lane holds
   // Z[q0 + 32 w + 16 qb + c16][32 s + 8 g .. +7]
-  constexpr int KS2 = KS / 2;
+  constexpr int KS2 = SPLITK ? KS / 4 : KS / 2;      // 32-wide k-steps this wave multiplies
+  const int kbyte = khalf * KS2 * 64;                // byte offset of its k range inside a row
   u32x4 qf[KS2][2];
   {
-    const char* qbase = reinterpret_cast<const char*>(a.ZQ) + (q0 + 32 * wave + c16) * (int64_t)ROWB + g * 16;
+    const char* qbase = reinterpret_cast<const char*>(a.ZQ) + (q0 + 32 * qw + c16) * (int64_t)ROWB + g * 16 + kbyte;
 #pragma unroll
     for (int s = 0; s < KS2; ++s) {
       qf[s][0] = *reinterpret_cast<const u32x4*>(qbase + s * 64);
@@ -389,6 +403,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
     if (l < 32) glds4(bsrc + l * 4u, cbs + stage * 64);
   };
 
+  if (SPLITK && tid < NQW) ack[tid] = -1;
   const int Ti = (int)T;
   if (Ti > 0) {   // first group of TPB tiles -> stages 0 .. TPB-1
 #pragma unroll
@@ -404,7 +419,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
   // into a stage nobody reads again — so no branch and no per-tile bookkeeping sits between the MFMAs.
   // (Issuing at different points of the chain for the two waves that share a SIMD used to pay when a piece cost
   // 64-bit address arithmetic; with the buffer form it measures 0.8 % slower than issuing at the same point.)
-  constexpr int GRP = KS2 / PPW;                     // k-steps (4 MFMAs each) between two DMA pieces
+  constexpr int GRP = KS2 / PPW;                     // k-steps (4 MFMAs each) between two DMA pieces (issuing the SPLITK
+                                                     // kernel's pieces in its first k-steps instead measured the same)
   static_assert(KS2 % PPW == 0 && GRP >= 1, "DMA piece placement");
   const char* tsrc = zc0 + TPB * (int64_t)TILEB;     // source of the first tile of the NEXT group
   const char* bsrc = cb0 + TPB * B_CT * 4;
@@ -415,7 +431,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
     Acc acc;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(cbt + 16 * cb + 4 * g);
+      f32x4 b4 = *reinterpret_cast<const f32x4*>(cbt + 16 * cb + 4 * g);
+      if (SPLITK && !owner) b4 = f32x4{0.f, 0.f, 0.f, 0.f};      // the bias is added once, by the lower-half wave
       acc.t[cb][0] = b4; acc.t[cb][1] = b4;
     }
     // A fragments are read PD k-steps ahead of the MFMAs that consume them (explicit register ring)
@@ -547,7 +564,21 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
     asm volatile("" ::: "memory");
     if (stamps) t1s = __builtin_amdgcn_s_memtime();
 
-    filter(acc_prev, j * TPB - 1, m0_prev, m1_prev);  // behind the barrier: only this wave waits for its own list code
+    if constexpr (SPLITK) {
+      if (owner) {
+        if (j > 0) {                 // the partner's half of tile j - 1, written before the barrier just passed
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const f32x4 p = xch[(qw * 4 + i) * 64 + lane];
+            acc_prev.t[i >> 1][i & 1] += p;
+          }
+          m0_prev = max_qb(acc_prev, 0);
+          m1_prev = max_qb(acc_prev, 1);
+        }
+        if (lane == 0) ack[qw] = j;  // the exchange block may be overwritten (LDS operations of a wave complete in order)
+      }
+    }
+    if (owner) filter(acc_prev, j * TPB - 1, m0_prev, m1_prev);  // behind the barrier: only this wave waits for its own list code
     if (stamps) t2s = __builtin_amdgcn_s_memtime();
 
     const int sg = (j & 1) * TPB, ng = TPB - sg;      // stage group read / filled by this iteration
@@ -557,7 +588,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
       const bool more = (t + TPB < Ti);
       const char* src = more ? tsrc + u * (int64_t)TILEB : zc0;
       Acc acc;
-      acc = tile_body(tiles + (sg + u) * TILEB, cbs + (sg + u) * 64, src, ng + u);
+      acc = tile_body(tiles + (sg + u) * TILEB + kbyte, cbs + (sg + u) * 64, src, ng + u);
       if (wave == ((t + TPB) & (NW - 1))) issue_bias(more ? bsrc + u * B_CT * 4 : cb0, ng + u);
       if (u < TPB - 1) {
         filter(acc, t, max_qb(acc, 0), max_qb(acc, 1));   // mid-iteration, no barrier nearby
@@ -570,8 +601,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
           }
         }
         acc_prev = acc;
-        m0_prev = max_qb(acc, 0);     // reduced BEFORE the barrier, in time this wave would otherwise spend waiting
-        m1_prev = max_qb(acc, 1);
+        if constexpr (!SPLITK) {
+          m0_prev = max_qb(acc, 0);     // reduced BEFORE the barrier, in time this wave would otherwise spend waiting
+          m1_prev = max_qb(acc, 1);
+        } else if (!owner) {
+          // hand this tile's partial sums to the lower-half wave once it has taken the previous tile's
+          while (ack[qw] < j) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xch[(qw * 4 + i) * 64 + lane] = acc.t[i >> 1][i & 1];
+          __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the partials are in LDS before this wave reaches the barrier
+        }
       }
     }
     tsrc += TPB * (int64_t)TILEB;
@@ -586,7 +625,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
     atomicAdd(a.dbg + 0, tw); atomicAdd(a.dbg + 1, tf); atomicAdd(a.dbg + 2, tc); atomicAdd(a.dbg + 3, (unsigned long long)Ti);
     atomicAdd(a.dbg + 8, tv);
   }
-  if (Ti > 0) filter(acc_prev, nIter * TPB - 1, max_qb(acc_prev, 0), max_qb(acc_prev, 1));
+  if constexpr (SPLITK) {               // the last tile's upper half
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();
+    if (owner && Ti > 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc_prev.t[i >> 1][i & 1] += xch[(qw * 4 + i) * 64 + lane];
+    }
+  }
+  if (Ti > 0 && owner) filter(acc_prev, nIter * TPB - 1, max_qb(acc_prev, 0), max_qb(acc_prev, 1));
   __builtin_amdgcn_s_waitcnt(0x0F70);   // the dummy tiles still in flight
 
   list.compact(a.kk, margin);
@@ -598,7 +645,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
       uint32_t id = list.id_of(e);
       if (a.seg_len) id = (id / a.seg_len) * a.seg_stride + id % a.seg_len;
       a.cand_ids[lbase * CAP + e] = id + a.id_off;
-      if (a.cand_keys) a.cand_keys[lbase * CAP + e] = list.keys[e * NT];
+      if (a.cand_keys) a.cand_keys[lbase * CAP + e] = list.keys[e * NTL];
     }
     // Audited loss, settled after the last launch: a dropped candidate matters only if its key reaches the
     // best threshold ANY list of the row has proven by then.
@@ -646,8 +693,10 @@ int launch_prep_half(const void* X, int64_t n, int64_t d, int dtype, int metric,
   return MMF_OK;
 }
 
-static size_t scan_b16_lds(int ks, int nw, int tpb, int cap) {
-  return (size_t)(2 * tpb) * (B_CT * ks * 32) + (size_t)(2 * tpb) * 64 * 4 + (size_t)cap * (64 * nw) * 4;
+static size_t scan_b16_lds(int ks, int nw, int tpb, int cap, bool splitk) {
+  const int nqw = splitk ? nw / 2 : nw;
+  return (size_t)(2 * tpb) * (B_CT * ks * 32) + (size_t)(2 * tpb) * 64 * 4 + (size_t)cap * (64 * nqw) * 4 +
+         (splitk ? (size_t)nqw * 4 * 64 * 16 + 64 : 0);
 }
 
 int scan_b16_queries_per_block(int dp) { return 32 * waves_for_dp(dp); }
@@ -674,9 +723,9 @@ size_t scan_b16_scratch_bytes(int64_t n_rows, int col_splits, int dp) {
   return (size_t)scan_b16_grid(n_rows, col_splits, dp) * 16 * (64 * waves_for_dp(dp)) * 4 + 256;
 }
 
-template <int KS, int NW, int TPB, int CAP>
+template <int KS, int NW, int TPB, int CAP, bool SPLITK = false>
 static int launch_b16_t(const ScanB16Args& a, bool f16, int64_t grid, hipStream_t s) {
-  const size_t lds = scan_b16_lds(KS, NW, TPB, CAP);
+  const size_t lds = scan_b16_lds(KS, NW, TPB, CAP, SPLITK);
   auto go = [&](auto kern) -> int {
     MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NW), lds, s, a);
@@ -684,11 +733,11 @@ static int launch_b16_t(const ScanB16Args& a, bool f16, int64_t grid, hipStream_
     return MMF_OK;
   };
   if (a.debug != 0) {   // instrumented build of the same kernel (MMF_SCAN_DEBUG)
-    if (f16) return go(scan_b16x_kernel<KS, true, true, NW, TPB, CAP>);
-    return go(scan_b16x_kernel<KS, false, true, NW, TPB, CAP>);
+    if (f16) return go(scan_b16x_kernel<KS, true, true, NW, TPB, CAP, SPLITK>);
+    return go(scan_b16x_kernel<KS, false, true, NW, TPB, CAP, SPLITK>);
   }
-  if (f16) return go(scan_b16x_kernel<KS, true, false, NW, TPB, CAP>);
-  return go(scan_b16x_kernel<KS, false, false, NW, TPB, CAP>);
+  if (f16) return go(scan_b16x_kernel<KS, true, false, NW, TPB, CAP, SPLITK>);
+  return go(scan_b16x_kernel<KS, false, false, NW, TPB, CAP, SPLITK>);
 }
 
 // Settles the audited losses of all scan launches of a problem (call once, after the last one).
@@ -744,7 +793,10 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
     case 128: rc = big ? launch_b16_t<8, 8, 1, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<8, 8, 2, B_CAP>(a, f16, grid, s); break;
     case 256: rc = big ? launch_b16_t<16, 8, 1, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<16, 8, 2, B_CAP>(a, f16, grid, s); break;
     case 512: rc = big ? launch_b16_t<32, 8, 1, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<32, 8, 2, B_CAP>(a, f16, grid, s); break;
-    case 1024: rc = big ? launch_b16_t<64, 4, 1, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<64, 4, 1, B_CAP>(a, f16, grid, s); break;
+    case 1024:
+      if (big || getenv("MMF_SCAN_NO_SPLITK")) rc = big ? launch_b16_t<64, 4, 1, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<64, 4, 1, B_CAP>(a, f16, grid, s);
+      else rc = launch_b16_t<64, 8, 1, B_CAP, true>(a, f16, grid, s);
+      break;
     default: set_error("scan_b16: unsupported padded dim %d", dp);
   }
   if (rc == MMF_OK && (a.debug & 16)) {

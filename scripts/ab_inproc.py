@@ -21,10 +21,13 @@ ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--prec", default="fast")
 ap.add_argument("--data", default="gaussian")
 ap.add_argument("--topk", type=int, default=5)
+ap.add_argument("--half", action="store_true", help="fp16 features")
 ap.add_argument("names", nargs="+")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 X = make_rows(0, a.rows, a.dim, dev, data=a.data)
+if a.half:
+    X = X.half()
 
 
 def use(name):
