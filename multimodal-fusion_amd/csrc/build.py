@@ -23,6 +23,10 @@ HEADERS = ["mmf_dev.h", "mmf_host.h", os.path.join(ROOT, "include", "mmf_hg.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-std=c++17", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function"]
+# Per-file extras.  The 16-bit scan takes maxima of MFMA results per tile; without -fno-honor-nans every fmaxf input is
+# canonicalised first (v_max x, x): 22 instead of 14 VALU instructions per tile, 1-2 % of the kernel.  Non-finite inputs
+# are outside the numerics contract, infinities are still honoured (-inf is the padding bias).
+EXTRA_FLAGS = {"mmf_scan_bf16.hip": ["-fno-honor-nans"]}
 
 
 def _newer(target: str, deps) -> bool:
@@ -46,7 +50,7 @@ def build(force: bool = False, jobs: int = 6, verbose: bool = False) -> str:
 
     def cc(job):
         sp, op = job
-        cmd = [HIPCC, *FLAGS, "-c", sp, "-o", op]
+        cmd = [HIPCC, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(sp), []), "-c", sp, "-o", op]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

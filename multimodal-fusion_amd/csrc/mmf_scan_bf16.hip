@@ -491,7 +491,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
   // falls into the (rare) list code then delays only itself while its SIMD partner issues MFMAs;
   // placed before the barrier it would hold all eight waves, and their matrix pipes, at the barrier.
   auto filter = [&](const Acc& acc, int tt, float m0, float m1) {
-    if (!(DBG && (a.debug & 1)) && __any((m0 >= thr_q0) || (m1 >= thr_q1))) {
+    if (__builtin_expect(!(DBG && (a.debug & 1)) && __any((m0 >= thr_q0) || (m1 >= thr_q1)), 0)) {
       const uint32_t id0 = id_base + (uint32_t)tt * B_CT;
       // this lane's query gets its 16 candidates together: its own 8 plus the 8 the partner lane holds
       f32x16 v;
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
       refresh_thr();
     }
     if (DBG && (a.debug & 8) && lane == 0) atomicAdd(a.dbg + 5, 1ull);   // tiles
-    if (a.share && (tt & 63) == 63) { sync_seed(); refresh_thr(); }
+    if (__builtin_expect(a.share && (tt & 63) == 63, 0)) { sync_seed(); refresh_thr(); }
   };
 
   // Main loop: TPB tiles per barrier.  Iteration j reads the group of stages holding tiles j*TPB ..
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
       if (u < TPB - 1) {
         filter(acc, t, max_qb(acc, 0), max_qb(acc, 1));   // mid-iteration, no barrier nearby
       } else {
-        if (t >= Ti) {              // ragged range: the last tile of the last group is a dummy
+        if (__builtin_expect(t >= Ti, 0)) {              // ragged range: the last tile of the last group is a dummy
 #pragma unroll
           for (int cb = 0; cb < 2; ++cb) {
 #pragma unroll
