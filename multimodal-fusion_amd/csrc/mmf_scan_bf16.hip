@@ -398,9 +398,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
                                              16, (int)src_off[i], (int)(uint32_t)(tsrc - zc0), 0, 0);
   };
   // the 32 biases of a tile: one 4-byte DMA by lanes 0..31 of the wave whose turn it is
+  // (buffer form like the tile pieces: the FLAT-encoded global form makes the compiler wait lgkmcnt(0) where the
+  // A-fragment ring wants counted waits)
+  const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(cb0), 0, -1, 0x00020000);
   auto issue_bias = [&](const char* bsrc, int stage) {
     const uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // lane id, no live VGPR
-    if (l < 32) glds4(bsrc + l * 4u, cbs + stage * 64);
+    if (l < 32)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, (__attribute__((address_space(3))) void*)(cbs + stage * 64), 4, (int)(l * 4u),
+                                               (int)(uint32_t)(bsrc - cb0), 0, 0);
   };
 
   if (SPLITK && tid < NQW) ack[tid] = -1;
@@ -587,8 +592,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
       const int t = j * TPB + u;
       const bool more = (t + TPB < Ti);
       const char* src = more ? tsrc + u * (int64_t)TILEB : zc0;
+      // the 32 biases of tile t + TPB go out BEFORE this tile's chain: issued behind it, the wave whose turn it is would
+      // reach the vmcnt(0) of the next iteration with a DMA just issued, and seven waves would wait for it at the barrier
       Acc acc;
       acc = tile_body(tiles + (sg + u) * TILEB + kbyte, cbs + (sg + u) * 64, src, ng + u);
+      // (behind the chain: issued in front of it, the same DMA costs +8 %; mid-chain needs a branch inside the chain)
       if (wave == ((t + TPB) & (NW - 1))) issue_bias(more ? bsrc + u * B_CT * 4 : cb0, ng + u);
       if (u < TPB - 1) {
         filter(acc, t, max_qb(acc, 0), max_qb(acc, 1));   // mid-iteration, no barrier nearby
