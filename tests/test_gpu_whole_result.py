@@ -111,3 +111,20 @@ def test_k16_and_clustered_rows_every_row(mmf):
     Xc = centers[assign] + 0.01 * torch.randn((65536, 512), generator=g, device="cuda") / 512 ** 0.5
     Xc = Xc / Xc.norm(dim=1, keepdim=True)
     whole_result(mmf, Xc, None, "neg_sq_l2", 5, True, oracle_rows=64)
+
+
+def test_c5_one_rank_of_eight_every_row(mmf):
+    """BASELINE C5 (N = 1048576, d = 1024, fp16 features) as rank 5 of 8 computes it: 131072 local rows against all
+    1 M columns — the split-k 16-bit scan against the exact f32 scan over every local row (2.7e14 flop each way)."""
+    N, d, P, r = 1048576, 1024, 8, 5
+    X = torch.empty((N, d), dtype=torch.float16, device="cuda")
+    for b in range(0, N, 65536):
+        g = torch.Generator(device="cuda").manual_seed(5000 + b)
+        blk = torch.randn((65536, d), generator=g, device="cuda", dtype=torch.float32)
+        X[b:b + 65536] = (blk / blk.norm(dim=1, keepdim=True)).half()
+    lo, hi = r * (N // P), (r + 1) * (N // P)
+    fi, fv, st = mmf.simtopk(X[lo:hi], X, metric="cosine", k=5, exclude_self=True, row_offset=lo, precision="fast", return_stats=True)
+    assert st["precision_used"] == 2
+    ei, ev = mmf.simtopk(X[lo:hi], X, metric="cosine", k=5, exclude_self=True, row_offset=lo, precision="exact")
+    bad = (fi != ei).any(dim=1) | (fv != ev).any(dim=1)
+    assert not bool(bad.any()), f"{int(bad.sum())} of {hi - lo} rows differ from the exact scan"
