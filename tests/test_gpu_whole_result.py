@@ -96,7 +96,7 @@ def test_c3_cross_modal_every_row(mmf):
 
 
 def test_d1024_fp16_features_every_row(mmf):
-    """The 4-wave d <= 1024 variant of the scan (BASELINE C5's shape) at N = 131072, fp16 features."""
+    """The d <= 1024 variant of the scan (split-k wave pairs; BASELINE C5's shape) at N = 131072, fp16 features."""
     X = make(131072, 1024, 5).half()
     whole_result(mmf, X, None, "cosine", 5, True, oracle_rows=64)
 
