@@ -599,6 +599,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
       // (behind the chain: issued in front of it, the same DMA costs +8 %; mid-chain needs a branch inside the chain)
       if (wave == ((t + TPB) & (NW - 1))) issue_bias(more ? bsrc + u * B_CT * 4 : cb0, ng + u);
       if (u < TPB - 1) {
+        if (TPB == 2 || __builtin_expect(t < Ti, 1))      // (TPB > 2: the ragged last group can hold several dummy tiles)
         filter(acc, t, max_qb(acc, 0), max_qb(acc, 1));   // mid-iteration, no barrier nearby
       } else {
         if (__builtin_expect(t >= Ti, 0)) {              // ragged range: the last tile of the last group is a dummy
@@ -798,8 +799,9 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
   int rc = MMF_E_INTERNAL;
   const bool big = (L.cap == B_CAP_BIG);   // k + self in 12..20: 16-entry lists, one tile per barrier
   switch (dp) {
-    case 128: rc = big ? launch_b16_t<8, 8, 1, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<8, 8, 2, B_CAP>(a, f16, grid, s); break;
-    case 256: rc = big ? launch_b16_t<16, 8, 1, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<16, 8, 2, B_CAP>(a, f16, grid, s); break;
+    // d <= 256: the smaller tiles leave room for eight stages — four tiles per barrier (-1.5 % against two at d = 256)
+    case 128: rc = big ? launch_b16_t<8, 8, 2, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<8, 8, 4, B_CAP>(a, f16, grid, s); break;
+    case 256: rc = big ? launch_b16_t<16, 8, 2, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<16, 8, 4, B_CAP>(a, f16, grid, s); break;
     case 512: rc = big ? launch_b16_t<32, 8, 1, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<32, 8, 2, B_CAP>(a, f16, grid, s); break;
     case 1024:
       if (big || getenv("MMF_SCAN_NO_SPLITK")) rc = big ? launch_b16_t<64, 4, 1, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<64, 4, 1, B_CAP>(a, f16, grid, s);
