@@ -66,8 +66,8 @@ extern "C" {
 /* candidate-generation precision for mmf_simtopk_ex.  The RESULT is identical in every mode
  * (final keys are always the canonical f32 chain); the mode only picks which MFMA pipe scans
  * the N x M pairs. */
-#define MMF_PREC_AUTO  0  /* FAST when the 16-bit scan supports the shape (d <= 1024 and k + self <= 20),
-                             else EXACT (any d, k + self <= 44)                                       */
+#define MMF_PREC_AUTO  0  /* FAST when the 16-bit scan supports the shape (d <= 1024 and k + self <= 20, or
+                             d <= 512 and k + self <= 44), else EXACT (any d, k + self <= 44)         */
 #define MMF_PREC_EXACT 1  /* v_mfma_f32_32x32x2_f32 scan, canonical keys in-kernel           */
 #define MMF_PREC_FAST  2  /* f16 MFMA scan (rows scaled by an exact power of two) with a proven error
                              margin + exact f32 re-rank; columns inside a row's margin that do not fit its

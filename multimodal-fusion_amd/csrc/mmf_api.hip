@@ -67,7 +67,8 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
                     int64_t d, bool f16, int metric, int kk, int col_splits, const CandLists& L, void* scratch,
                     const ScanB16Panel& pn, hipStream_t s, int* grid_out);
 int launch_scan_b16_audit(const ScanB16Panel& pn, uint32_t* overflow, int64_t n_rows, hipStream_t s);
-size_t scan_b16_scratch_bytes(int64_t n_rows, int col_splits, int dp);
+size_t scan_b16_scratch_bytes(int64_t n_rows, int col_splits, int dp, int cap);
+int scan_bf16_slot_ulp(int cap);
 int scan_b16_queries_per_block(int dp);
 
 static int check_common(const void* X, int64_t n, int64_t m, int64_t d, int in_dtype, int device_id) {
@@ -221,7 +222,7 @@ struct FastTail {
   size_t bytes() const {
     return ws_bytes((size_t)n * lists, 4) + 2 * ws_bytes((size_t)n * lists * bcap, 4) + 3 * ws_bytes(n, 4) + ws_bytes(4, 4) +
            ws_bytes(256, 4) + ws_bytes((size_t)FB * fb_lists, 4) + ws_bytes((size_t)FB * fb_lists * cap, 4) +
-           2 * ws_bytes(FB, 4) + ws_bytes(4, 4) + ws_bytes(scan_b16_scratch_bytes(n, max_splits, dp), 1) + ws_bytes(2 * n_seed, 4) +
+           2 * ws_bytes(FB, 4) + ws_bytes(4, 4) + ws_bytes(scan_b16_scratch_bytes(n, max_splits, dp, bcap), 1) + ws_bytes(2 * n_seed, 4) +
            ws_bytes((size_t)rows_exact_cap * m, 4) + ws_bytes(n, 4) + ws_bytes((size_t)n * kSpillCap, 4) + ws_bytes(n, 4) + ws_bytes(4, 4);
   }
   void carve(Workspace& ws) {
@@ -230,7 +231,7 @@ struct FastTail {
     L.keys = ws.take<float>((size_t)n * lists * bcap);
     L.margin = ws.take<float>(n);
     L.overflow = ws.take<uint32_t>(n);
-    L.lists = lists; L.cap = bcap;
+    L.lists = lists; L.cap = bcap; L.slot_ulp = scan_bf16_slot_ulp(bcap);
     fail_rows = ws.take<int32_t>(n);
     fail_count = ws.take<uint32_t>(4);
     cand_total = ws.take<uint32_t>(256);
@@ -240,7 +241,7 @@ struct FastTail {
     FL.lists = fb_lists; FL.cap = cap;
     fb_fail_rows = ws.take<int32_t>(FB);
     fb_fail_count = ws.take<uint32_t>(4);
-    scan_scratch = ws.take<char>(scan_b16_scratch_bytes(n, max_splits, dp));
+    scan_scratch = ws.take<char>(scan_b16_scratch_bytes(n, max_splits, dp, bcap));
     seed = ws.take<int32_t>(2 * n_seed);
     if (lists <= 2) { L.keys = nullptr; L.margin = nullptr; }    // one list pair per row: nothing to prune against
     row_keys = ws.take<float>((size_t)rows_exact_cap * m);
@@ -698,6 +699,10 @@ int mmf_simtopk_panels(const void* X, int64_t n, const void* Y, int64_t m, int64
   DeviceGuard guard(device_id);
   if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
   FastTail ft(n, m, kk, cap, opts ? opts->col_splits : 0, scan_bf16_dp(d), n_panels, m_min);
+  if ((int64_t)ft.lists * ft.bcap + FastTail::kSpillCap > 1024) {
+    set_error("simtopk_panels: %d panels x %d-entry lists exceed the 1024 candidates a row can hand to the re-rank (k = %d): use fewer panels", n_panels, ft.bcap, k);
+    return MMF_E_UNSUPPORTED;
+  }
   Workspace ws;
   MMF_TRY(get_workspace(device_id, s, ft.bytes(), &ws));
   ft.carve(ws);

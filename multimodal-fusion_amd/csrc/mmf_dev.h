@@ -288,22 +288,46 @@ struct LaneList {
     cnt = w;
   }
 
-  // CAP > 16 (large k, rare; CAP <= 64): ranks by counting straight out of LDS; the partner's list is read in
-  // place (same wave, so its LDS writes are already ordered before these reads).
+  // CAP > 16 (large k; CAP <= 64): ranks by counting straight out of LDS; the partner's list is read in place (same
+  // wave, so its LDS writes are already ordered before these reads).  Eight entries are ranked per sweep over the
+  // two lists: one pair of ds_reads feeds eight compares, and the reads of a sweep pipeline (one entry per sweep
+  // waited for every read).  The total order (key desc, id asc) is one signed 64-bit compare of
+  // (order-preserving key bits : ~id); -0.0 is folded into +0.0 first, as the float compare of better() does.
+  static __device__ __forceinline__ long long order64(float key, uint32_t id) {
+    const int b = __float_as_int(key + 0.0f);
+    const int e = b >= 0 ? b : (b ^ 0x7fffffff);
+    return (long long)(((unsigned long long)(uint32_t)e << 32) | (unsigned long long)(~id));
+  }
   template <bool EXACT>
   __device__ __forceinline__ void compact_ranked(int kk, float margin) {
+    constexpr int BLK = 8;
     const int pofs = (int)((threadIdx.x ^ 32u) - threadIdx.x);
     const int pcnt = __shfl_xor(cnt, 32);
     unsigned long long topmask = 0;
     float t_own = kNegInf;
-    for (int e = 0; e < cnt; ++e) {
-      const float ke = keys[e * NT];
-      const uint32_t ie = ids[e * NT];
-      int r_own = 0, r_par = 0;
-      for (int f = 0; f < cnt; ++f) r_own += better(keys[f * NT], ids[f * NT], ke, ie) ? 1 : 0;
-      for (int f = 0; f < pcnt; ++f) r_par += better(keys[f * NT + pofs], ids[f * NT + pofs], ke, ie) ? 1 : 0;
-      if (r_own + r_par == kk - 1) t_own = ke;
-      if (r_own < kk) topmask |= 1ull << e;
+    for (int e0 = 0; e0 < cnt; e0 += BLK) {
+      float kf32[BLK]; long long ke[BLK]; int ro[BLK], rp[BLK];
+#pragma unroll
+      for (int i = 0; i < BLK; ++i) {                   // rows beyond cnt: stale but inside the lane's column; masked below
+        const int e = (e0 + i < CAP) ? e0 + i : CAP - 1;
+        kf32[i] = keys[e * NT]; ke[i] = order64(kf32[i], ids[e * NT]); ro[i] = 0; rp[i] = 0;
+      }
+      for (int f = 0; f < cnt; ++f) {
+        const long long kf = order64(keys[f * NT], ids[f * NT]);
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) ro[i] += (kf > ke[i]) ? 1 : 0;
+      }
+      for (int f = 0; f < pcnt; ++f) {
+        const long long kf = order64(keys[f * NT + pofs], ids[f * NT + pofs]);
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) rp[i] += (kf > ke[i]) ? 1 : 0;
+      }
+#pragma unroll
+      for (int i = 0; i < BLK; ++i) {
+        const bool live = e0 + i < cnt;
+        if (live && ro[i] + rp[i] == kk - 1) t_own = kf32[i];
+        if (live && ro[i] < kk) topmask |= 1ull << (e0 + i);
+      }
     }
     const float t = fmaxf(t_own, __shfl_xor(t_own, 32));
     raise_thr(t, margin, EXACT);
@@ -386,7 +410,10 @@ struct SpillSink {
 
 template <int CAP, int NT>
 struct SlotList {
-  static_assert(CAP <= 16, "4 slot bits");
+  static_assert(CAP <= 32, "at most 5 slot bits");
+  static constexpr int SLOTBITS = (CAP <= 16) ? 4 : 5;          // low mantissa bits of a stored key that carry its id slot
+  static constexpr uint32_t SLOTMASK = (1u << SLOTBITS) - 1u;
+  static constexpr int SLOTS = 1 << SLOTBITS;                  // id slots per lane in the global slot block
   SpillSink sink;
   float* keys;        // LDS, offset by threadIdx.x
   uint32_t* idslot;   // global, offset by threadIdx.x
@@ -405,12 +432,12 @@ struct SlotList {
   __device__ __forceinline__ void push(float key, uint32_t id) {   // requires cnt < CAP
     const int sl = __builtin_ctz(~used);
     idslot[sl * NT] = id;
-    keys[cnt * NT] = __uint_as_float((__float_as_uint(key) & ~15u) | (uint32_t)sl);
+    keys[cnt * NT] = __uint_as_float((__float_as_uint(key) & ~SLOTMASK) | (uint32_t)sl);
     used |= 1u << sl;
     ++cnt;
   }
   __device__ __forceinline__ uint32_t id_of(int e) const {          // entry e -> column id (global read)
-    return idslot[(__float_as_uint(keys[e * NT]) & 15u) * NT];
+    return idslot[(__float_as_uint(keys[e * NT]) & SLOTMASK) * NT];
   }
   __device__ __forceinline__ void raise_thr(float t, float margin) {
     const float nthr = (t == kNegInf) ? -kFltMax : (t - margin);
@@ -420,6 +447,7 @@ struct SlotList {
   // wave-wide; leaves at least two free slots (what it has to give up for that goes to the sink, or — without
   // one, or with the sink full — is recorded in `lost`)
   __device__ __forceinline__ void compact(int kk, float margin) {
+    if constexpr (CAP > 16) { compact_ranked(kk, margin); return; }
     float k[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) k[e] = ((e < CAP) && (e < cnt)) ? keys[(e < CAP ? e : 0) * NT] : kNegInf;
@@ -484,9 +512,82 @@ struct SlotList {
     for (int e = 0; e < cnt; ++e) {     // in-place filter of the LDS keys, lane-private
       const float ke = keys[e * NT];
       if (ke >= cut && w < room) {
-        keys[w * NT] = ke; nused |= 1u << (__float_as_uint(ke) & 15u); ++w;
+        keys[w * NT] = ke; nused |= 1u << (__float_as_uint(ke) & SLOTMASK); ++w;
       } else if (ke >= thr) {           // still inside the band: to the overflow list, else lost (audited)
-        if (!sink.put(idslot[(__float_as_uint(ke) & 15u) * NT])) lost = fmaxf(lost, ke);
+        if (!sink.put(idslot[(__float_as_uint(ke) & SLOTMASK) * NT])) lost = fmaxf(lost, ke);
+      }
+    }
+    thr = fmaxf(thr, lost);
+    used = nused;
+    cnt = w;
+  }
+
+  // CAP > 16 (k + self in 21..44): no sorting network — a lane's 32 keys do not fit registers beside the query
+  // fragments.  Every entry is ranked by counting straight out of LDS, against its own list and the partner lane's
+  // (same wave: its LDS writes are ordered before these reads), eight entries per sweep so that one ds_read feeds eight
+  // compares and the reads of a sweep pipeline.  Keys of one list differ in their slot bits; a key equal to one of
+  // the partner list's ranks behind it in the upper lane half only, so exactly one entry of the union has rank
+  // kk - 1.  The union the threshold sees is what the two lists HOLD: a key that has moved to the overflow list no
+  // longer counts, which can only make the threshold lower (still valid).
+  static __device__ __forceinline__ int key_enc(float x) {          // order-preserving float -> int
+    const int b = __float_as_int(x);
+    return b >= 0 ? b : (b ^ 0x7fffffff);
+  }
+  __device__ __forceinline__ void compact_ranked(int kk, float margin) {
+    constexpr int BLK = 8;
+    const int pofs = (int)((threadIdx.x ^ 32u) - threadIdx.x);
+    const int pcnt = __shfl_xor(cnt, 32);
+    const int tie = (threadIdx.x & 32u) ? 1 : 0;       // upper lane half: an equal partner key ranks first
+    const int room_crowded = (kk + 2 < CAP - 2) ? (kk + 2) : (CAP - 2);
+    uint32_t own_top = 0;                               // entries whose rank inside THIS list is below room_crowded
+    float t_own = kNegInf;
+    for (int e0 = 0; e0 < cnt; e0 += BLK) {
+      float kf32[BLK]; int ke[BLK], ro[BLK], rp[BLK];
+#pragma unroll
+      for (int i = 0; i < BLK; ++i) {                   // e0 + i < CAP: inside the lane's column (stale beyond cnt, masked below)
+        kf32[i] = keys[(e0 + i) * NT]; ke[i] = key_enc(kf32[i]); ro[i] = 0; rp[i] = 0;
+      }
+      for (int f = 0; f < cnt; ++f) {
+        const int kf = key_enc(keys[f * NT]);
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) ro[i] += (kf > ke[i]) ? 1 : 0;
+      }
+      for (int f = 0; f < pcnt; ++f) {
+        const int kf = key_enc(keys[f * NT + pofs]) + tie;
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) rp[i] += (kf > ke[i]) ? 1 : 0;
+      }
+#pragma unroll
+      for (int i = 0; i < BLK; ++i) {
+        const bool live = e0 + i < cnt;
+        if (live && ro[i] + rp[i] == kk - 1) t_own = kf32[i];
+        if (live && ro[i] < room_crowded) own_top |= 1u << (e0 + i);
+      }
+    }
+    const float t = fmaxf(t_own, __shfl_xor(t_own, 32));
+    raise_thr(t, margin);
+    int keep = 0;
+    for (int e0 = 0; e0 < cnt; e0 += BLK) {
+#pragma unroll
+      for (int i = 0; i < BLK; ++i) keep += ((e0 + i < cnt) && keys[(e0 + i) * NT] >= thr) ? 1 : 0;
+    }
+    const bool crowded = keep >= CAP - 1;               // only the lane's best room_crowded entries stay then
+    int w = 0;
+    uint32_t nused = 0;
+    for (int e0 = 0; e0 < cnt; e0 += BLK) {             // in-place filter: a block is in registers before it is overwritten
+      float kb[BLK];
+#pragma unroll
+      for (int i = 0; i < BLK; ++i) kb[i] = keys[(e0 + i) * NT];
+#pragma unroll
+      for (int i = 0; i < BLK; ++i) {
+        const float ke = kb[i];
+        const bool live = (e0 + i < cnt) && (ke >= thr);
+        const bool stay = live && (!crowded || ((own_top >> (e0 + i)) & 1u));
+        if (stay && w < CAP - 2) {
+          keys[w * NT] = ke; nused |= 1u << (__float_as_uint(ke) & SLOTMASK); ++w;
+        } else if (live) {
+          if (!sink.put(idslot[(__float_as_uint(ke) & SLOTMASK) * NT])) lost = fmaxf(lost, ke);
+        }
       }
     }
     thr = fmaxf(thr, lost);

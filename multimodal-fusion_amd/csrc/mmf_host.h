@@ -92,6 +92,7 @@ struct CandLists {
   // lists per row, select drops what the union of the lists proves irrelevant before the exact re-rank
   float* keys = nullptr;
   float* margin = nullptr;   // [n]
+  int slot_ulp = 16;         // stored keys carry an id-slot number in their low mantissa bits: 16 (4 bits) or 32 (5 bits)
   // 16-bit scan only: per-row overflow lists (SpillSink, mmf_dev.h) — what the lane lists could not hold
   uint32_t* spill_cnt = nullptr;   // [n], zeroed before the first launch
   uint32_t* spill_ids = nullptr;   // [n][spill_cap], GLOBAL-mapped local column ids like `ids`

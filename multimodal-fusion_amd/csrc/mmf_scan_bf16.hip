@@ -46,6 +46,8 @@ constexpr int B_CT = 32;
 constexpr int B_CAP = MMF_B_CAP;  // list entries per lane for k + self <= 11: what LDS leaves beside four 32 KiB tile stages
 constexpr int B_CAP_BIG = 16;     // ... for k + self in 12..20 (costs the fourth tile stage: TPB = 1); what a lane list
                                   // cannot hold goes to the row's overflow list, so the capacity bounds speed, not k
+constexpr int B_CAP_WIDE = 32;    // ... for k + self in 21..44, d <= 512: 5 slot bits, ranks counted out of LDS (64 KiB of lists
+                                  // beside two 32 KiB tile stages)
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
   // Candidate lists (SlotList, mmf_dev.h): approximate keys in LDS, column ids in a global slot block of
   // this workgroup — leaving most of LDS to the tile ring is what buys the fourth stage.
   float* lkeys = cbs + STAGES * 64;                                  // [CAP][NTL]
-  uint32_t* lids = a.lids + (size_t)blockIdx.x * (16 * NTL);
+  uint32_t* lids = a.lids + (size_t)blockIdx.x * (SlotList<CAP, NTL>::SLOTS * NTL);
   f32x4* xch = reinterpret_cast<f32x4*>(lkeys + CAP * NTL);          // SPLITK: [NQW][4][64] partial accumulators
   volatile int* ack = reinterpret_cast<volatile int*>(xch + NQW * 4 * 64);   // SPLITK: [NQW] last tile the lower wave took
 
@@ -311,8 +313,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
     const float zn = a.q_zn[qpos], rn = a.q_rn[qpos], un = a.q_un[qpos];   // arrays are padded
     const float g_acc = (float)(KS * 16 + 8) * 5.9604645e-8f;
     const float g_chain = (float)(a.d + 2) * 5.9604645e-8f;
-    // + 2^-19 |G|: the 4 slot bits a stored key carries in its low mantissa bits (SlotList)
-    const float e1 = rn * ZB + un * RB + (g_acc + 1.9073486e-6f) * (zn * ZB + CB);
+    // + 2^-19 |G| (2^-18 with 5 slot bits): the slot number a stored key carries in its low mantissa bits (SlotList)
+    const float slot_eps = (CAP <= 16) ? 1.9073486e-6f : 3.8146973e-6f;
+    const float e1 = rn * ZB + un * RB + (g_acc + slot_eps) * (zn * ZB + CB);
     float e2;
     if (a.metric == MMF_DOT) e2 = g_chain * un * UB;
     else if (a.metric == MMF_COSINE) e2 = (g_chain + 4.7683716e-7f) * un * UB * 1.01f;
@@ -659,7 +662,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
     // Audited loss, settled after the last launch: a dropped candidate matters only if its key reaches the
     // best threshold ANY list of the row has proven by then.
     if (a.cand_keys && half == 0) a.margin_out[qpos] = margin;
-    if (list.lost > kNegInf) atomicMax(a.lost + qpos, seed_enc(list.lost) + 16);   // +16 ulp: stored keys carry slot bits
+    if (list.lost > kNegInf) atomicMax(a.lost + qpos, seed_enc(list.lost) + SlotList<CAP, NTL>::SLOTS);   // stored keys carry slot bits
   }
 }
 
@@ -685,10 +688,14 @@ static int waves_for_dp(int dp) { return dp <= 512 ? 8 : 4; }   // workgroup sha
 
 int scan_bf16_supported(int64_t d, int kk, int dtype) {
   (void)dtype;
-  return (pad_dp(d) != 0 && kk <= 20) ? 1 : 0;     // two 16-entry lists per query keep 14 each after a compaction
+  const int dp = pad_dp(d);
+  if (dp == 0) return 0;
+  if (kk <= 20) return 1;                          // two 16-entry lists per query keep 14 each after a compaction
+  return (kk <= 44 && dp <= 512) ? 1 : 0;          // two 32-entry lists (their 64 KiB do not fit beside 64 KiB tiles: d <= 512)
 }
 
-int scan_bf16_cap(int kk) { return kk <= B_CAP - 4 ? B_CAP : B_CAP_BIG; }
+int scan_bf16_cap(int kk) { return kk <= B_CAP - 4 ? B_CAP : (kk <= 20 ? B_CAP_BIG : B_CAP_WIDE); }
+int scan_bf16_slot_ulp(int cap) { return cap <= 16 ? 16 : 32; }
 int scan_bf16_dp(int64_t d) { return pad_dp(d); }
 
 int launch_prep_half(const void* X, int64_t n, int64_t d, int dtype, int metric, const float* scal,
@@ -727,9 +734,9 @@ static int64_t scan_b16_grid(int64_t n_rows, int col_splits, int dp) {
   return scan_b16_round_blocks(row_blocks, cs) * (col_splits / cs);
 }
 
-// bytes of the global id-slot scratch ([grid][16][threads] u32) a launch needs
-size_t scan_b16_scratch_bytes(int64_t n_rows, int col_splits, int dp) {
-  return (size_t)scan_b16_grid(n_rows, col_splits, dp) * 16 * (64 * waves_for_dp(dp)) * 4 + 256;
+// bytes of the global id-slot scratch ([grid][slots][list threads] u32) a launch needs
+size_t scan_b16_scratch_bytes(int64_t n_rows, int col_splits, int dp, int cap) {
+  return (size_t)scan_b16_grid(n_rows, col_splits, dp) * (cap <= 16 ? 16 : 32) * (64 * waves_for_dp(dp)) * 4 + 256;
 }
 
 template <int KS, int NW, int TPB, int CAP, bool SPLITK = false>
@@ -798,6 +805,14 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
   if (grid_out) *grid_out = (int)grid;
   int rc = MMF_E_INTERNAL;
   const bool big = (L.cap == B_CAP_BIG);   // k + self in 12..20: 16-entry lists, one tile per barrier
+  if (L.cap == B_CAP_WIDE) {               // k + self in 21..44: 32-entry lists, one tile per barrier, d <= 512
+    switch (dp) {
+      case 128: rc = launch_b16_t<8, 8, 1, B_CAP_WIDE>(a, f16, grid, s); break;
+      case 256: rc = launch_b16_t<16, 8, 1, B_CAP_WIDE>(a, f16, grid, s); break;
+      case 512: rc = launch_b16_t<32, 8, 1, B_CAP_WIDE>(a, f16, grid, s); break;
+      default: set_error("scan_b16: 32-entry lists need a padded dim <= 512 (got %d)", dp);
+    }
+  } else
   switch (dp) {
     // d <= 256: the smaller tiles leave room for eight stages — four tiles per barrier (-1.5 % against two at d = 256)
     case 128: rc = big ? launch_b16_t<8, 8, 2, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<8, 8, 4, B_CAP>(a, f16, grid, s); break;

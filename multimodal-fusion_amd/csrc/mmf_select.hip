@@ -23,6 +23,7 @@ struct SelectArgs {
   const int32_t* row_ids; int64_t n_rows;
   const uint32_t* cand_cnt; const uint32_t* cand_ids; const uint32_t* overflow; int lists; int cap;
   const float* cand_keys; const float* margin;      // optional: approximate keys of the entries + the row's error margin
+  int slot_ulp;                                     // ... which carry this many ulps of id-slot bits
   const uint32_t* spill_cnt; const uint32_t* spill_ids; int spill_cap;   // optional: the row's overflow list
   // staged kernel, two passes when overflow lists exist: pass 0 handles the rows without overflow entries in a lean
   // LDS footprint and queues the others; pass 1 (room for the overflow entries) takes the queue
@@ -135,7 +136,7 @@ __device__ __forceinline__ int gather_candidates(const SelectArgs& a, int64_t po
     uint32_t ie = 0;
     if (e < total) {
       const int32_t b = __float_as_int(key[e]);
-      keep = ((b >= 0 ? b : (b ^ 0x7fffffff)) + 16) >= thr_enc;
+      keep = ((b >= 0 ? b : (b ^ 0x7fffffff)) + a.slot_ulp) >= thr_enc;
       ie = id[e];
     }
     __builtin_amdgcn_wave_barrier();
@@ -434,7 +435,7 @@ int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
   a.row_offset = p.row_offset; a.col_offset = p.col_offset; a.rx = p.rx; a.cy = p.cy;
   a.row_ids = p.row_ids; a.n_rows = p.n_rows;
   a.cand_cnt = L.cnt; a.cand_ids = L.ids; a.overflow = L.overflow; a.lists = L.lists; a.cap = L.cap;
-  a.cand_keys = L.keys; a.margin = L.margin;
+  a.cand_keys = L.keys; a.margin = L.margin; a.slot_ulp = L.slot_ulp;
   a.spill_cnt = L.spill_cnt; a.spill_ids = L.spill_ids; a.spill_cap = L.spill_cap;
   a.pass = 0; a.defer_rows = p.defer_rows; a.defer_count = p.defer_count;
   a.out_idx = p.out_idx; a.out_val = p.out_val;

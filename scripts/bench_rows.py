@@ -70,7 +70,7 @@ for name, fn in (("matrix only", lambda: ops.sim_dense(A, B, metric="rbf_direct"
         "ms": t * 1e3, "bound": "valu (v_sub + v_fma per pair-k)", "pair-k/s": work / t, "frac": work / t / VALU_PAIRK,
         "write GB/s": 0.0 if "never" in name else N * M * 4 / t / 1e9}
 del A, B
-# a8 (exact): the f32 MFMA scan — precision="exact", the AUTO path for d > 1024 or k + self > 20, and the rescan of flagged rows
+# a8 (exact): the f32 MFMA scan — precision="exact", the AUTO path for d > 1024 (d > 512 when k + self > 20), and the rescan of flagged rows
 N3 = 65536
 X3 = rows(N3, d, 4)
 t = timed(lambda: mmf.simtopk(X3, metric="cosine", k=5, precision="exact"), reps=3, warm=1)

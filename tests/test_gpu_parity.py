@@ -74,9 +74,9 @@ def test_simtopk_self_exact(mmf, metric, n, d, k):
 @pytest.mark.parametrize("metric", ["cosine", "neg_sq_l2"])
 @pytest.mark.parametrize("n,d,k,exclude", [(400, 64, 28, True), (400, 64, 32, True), (3000, 128, 32, True), (3000, 128, 43, True),
                                            (700, 96, 44, False), (5000, 256, 33, True)])
-def test_simtopk_large_k_on_the_exact_scan(mmf, metric, n, d, k, exclude):
+def test_simtopk_large_k(mmf, metric, n, d, k, exclude):
     """sklearn's NearestNeighbors has no cap on n_neighbors (preprocess_hypergraph.py:379); the exact scan's 48-entry
-    lists carry k + self up to 44, AUTO routes there beyond what the 16-bit scan's lists hold."""
+    lists carry k + self up to 44, and so do the 16-bit scan's 32-entry list pairs for d <= 512 (AUTO's choice)."""
     X = unit_rows(n, d, 100 + n + k).numpy()
     if exclude:
         check_topk(mmf, X, None, metric, k, precision="exact")
@@ -86,6 +86,50 @@ def test_simtopk_large_k_on_the_exact_scan(mmf, metric, n, d, k, exclude):
         check_topk(mmf, X, Y, metric, k, precision="auto")
     with pytest.raises(RuntimeError, match="supported maximum"):
         mmf.simtopk(dev(X), metric=metric, k=45)
+
+
+@pytest.mark.parametrize("metric", ["dot", "cosine", "neg_sq_l2", "rbf"])
+@pytest.mark.parametrize("n,d,k", [(300, 32, 20), (1000, 128, 21), (3000, 128, 32), (2049, 512, 27), (5000, 256, 43), (777, 500, 40)])
+def test_simtopk_large_k_fast_lists(mmf, metric, n, d, k):
+    """k + self in 21..44 on the 16-bit scan: 32-entry lane lists with 5 slot bits (d <= 512)."""
+    X = unit_rows(n, d, 300 + n + k).numpy()
+    for prec in ("fast", "fast_bf16"):
+        check_topk(mmf, X, None, metric, k, precision=prec)
+    _, _, st = mmf.simtopk(dev(X), metric=metric, k=k, return_stats=True)
+    assert st["precision_used"] == 2, st          # AUTO takes it too
+
+
+def test_simtopk_large_k_fast_splits_offsets_duplicates(mmf):
+    X = unit_rows(4096, 128, 6).numpy()
+    full_i, full_v = oracle.simtopk(X, metric="cosine", k=30)
+    for splits in (1, 2, 8, 16):
+        i, v, st = mmf.simtopk(dev(X), metric="cosine", k=30, precision="fast", col_splits=splits, return_stats=True)
+        assert np.array_equal(i.cpu().numpy(), full_i) and np.array_equal(v.cpu().numpy(), full_v), splits
+        assert st["fallback_rows"] == 0, (splits, st)
+    i, v = mmf.simtopk(dev(X[1000:1777]), dev(X), metric="cosine", k=30, exclude_self=True, row_offset=1000, precision="fast")
+    assert np.array_equal(i.cpu().numpy(), full_i[1000:1777]) and np.array_equal(v.cpu().numpy(), full_v[1000:1777])
+    # cross-modal, no self: k + self = k
+    Y = unit_rows(3000, 128, 8).numpy()
+    check_topk(mmf, X[:900], Y, "neg_sq_l2", 44, precision="fast", exclude_self=False)
+    # 60 exact copies of 10 rows: ties fill the lists, the overflow lists take the rest, ids break the ties
+    D = np.repeat(rnd(10, 64, 3), 60, axis=0)
+    idx, val, st = mmf.simtopk(dev(D), metric="neg_sq_l2", k=25, precision="fast", return_stats=True)
+    ridx, rval = oracle.simtopk(D, metric="neg_sq_l2", k=25)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(val.cpu().numpy(), rval)
+    assert st["precision_used"] == 2
+    # a tight cluster inside a random set
+    X = unit_rows(3000, 128, 77).numpy()
+    X[100:200] = X[100] + 1e-4 * rnd(100, 128, 78)
+    ridx, rval = oracle.simtopk(X, metric="cosine", k=24)
+    for splits in (1, 0):
+        idx, val, st = mmf.simtopk(dev(X), metric="cosine", k=24, precision="fast", col_splits=splits, return_stats=True)
+        assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(val.cpu().numpy(), rval)
+    # d > 512 keeps large k on the exact scan; asking for the 16-bit scan there is an error
+    Z = unit_rows(600, 700, 9).numpy()
+    _, _, st = mmf.simtopk(dev(Z), metric="cosine", k=30, return_stats=True)
+    assert st["precision_used"] == 1
+    with pytest.raises(RuntimeError, match="does not support"):
+        mmf.simtopk(dev(Z), metric="cosine", k=30, precision="fast")
 
 
 # the bf16 MFMA scan + exact re-rank must give the SAME bits as the exact scan and the oracle

@@ -128,3 +128,15 @@ def test_c5_one_rank_of_eight_every_row(mmf):
     ei, ev = mmf.simtopk(X[lo:hi], X, metric="cosine", k=5, exclude_self=True, row_offset=lo, precision="exact")
     bad = (fi != ei).any(dim=1) | (fv != ev).any(dim=1)
     assert not bool(bad.any()), f"{int(bad.sum())} of {hi - lo} rows differ from the exact scan"
+
+
+def test_k32_wide_lists_every_row(mmf):
+    """The 32-entry-list variant of the 16-bit scan (k + self = 33) against the exact scan, Gaussian and clustered."""
+    X = make(65536, 512, 78)
+    whole_result(mmf, X, None, "cosine", 32, True, oracle_rows=32)
+    g = torch.Generator(device="cuda").manual_seed(8)
+    centers = make(2048, 256, 4)
+    assign = torch.randint(0, 2048, (32768,), generator=g, device="cuda")
+    Xc = centers[assign] + 0.03 * torch.randn((32768, 256), generator=g, device="cuda") / 256 ** 0.5
+    Xc = Xc / Xc.norm(dim=1, keepdim=True)
+    whole_result(mmf, Xc, None, "neg_sq_l2", 24, True, precisions=("fast",), oracle_rows=32)
