@@ -23,11 +23,13 @@ void set_error(const char* fmt, ...) {
 
 struct WsEntry { char* base = nullptr; size_t cap = 0; };
 static std::mutex g_ws_mu;
-static std::map<std::pair<int, hipStream_t>, WsEntry> g_ws;
+static std::map<std::pair<int, hipStream_t>, WsEntry> g_ws[2];
 
-int get_workspace(int device, hipStream_t stream, size_t bytes, Workspace* out) {
+// slot 0: the call's working set.  slot 1: what only a rare branch of a call needs on top of it (the f32 operand
+// images of an exact rescan inside the 16-bit path), so that every call does not carry it.
+static int get_workspace_slot(int device, hipStream_t stream, int slot, size_t bytes, Workspace* out) {
   std::lock_guard<std::mutex> lk(g_ws_mu);
-  WsEntry& e = g_ws[std::make_pair(device, stream)];
+  WsEntry& e = g_ws[slot][std::make_pair(device, stream)];
   if (e.cap < bytes) {
     if (e.base) {
       MMF_HIP(hipStreamSynchronize(stream));
@@ -50,6 +52,7 @@ int get_workspace(int device, hipStream_t stream, size_t bytes, Workspace* out) 
   out->off = 0;
   return MMF_OK;
 }
+int get_workspace(int device, hipStream_t stream, size_t bytes, Workspace* out) { return get_workspace_slot(device, stream, 0, bytes, out); }
 
 int launch_edge_cosine_impl(const void* X, int64_t d, int dtype, const float* nrm, const int64_t* ei, int64_t E,
                             float* out, hipStream_t s);
@@ -334,13 +337,25 @@ struct FastTail {
         fq.n_rows = ((int64_t)h_fail - off < rows_exact_cap) ? ((int64_t)h_fail - off) : rows_exact_cap;
         MMF_TRY(launch_rows_exact(fq, row_keys, s));
       }
-    } else
+    } else {
+    float *fb_Xp = nullptr, *fb_Yp = nullptr;
+    int dev_now = 0;
+    MMF_HIP(hipGetDevice(&dev_now));
     for (int64_t off = 0; off < (int64_t)h_fail; off += FB) {
       const int64_t nb = ((int64_t)h_fail - off < FB) ? ((int64_t)h_fail - off) : FB;
+      if (off == 0) {   // f32 operand images for the exact scan: all candidate rows once, the flagged rows per batch
+        Workspace aux;
+        MMF_TRY(get_workspace_slot(dev_now, s, 1, ws_bytes(prep_f32_bytes(m, d), 1) + ws_bytes(prep_f32_bytes(FB, d), 1), &aux));
+        fb_Yp = reinterpret_cast<float*>(aux.take<char>(prep_f32_bytes(m, d)));
+        fb_Xp = reinterpret_cast<float*>(aux.take<char>(prep_f32_bytes(FB, d)));
+        MMF_TRY(launch_prep_f32(Y, m, d, in_dtype, nullptr, fb_Yp, s));
+      }
+      MMF_TRY(launch_prep_f32(X, nb, d, in_dtype, fail_rows + off, fb_Xp, s));
       MMF_HIP(hipMemsetAsync(FL.overflow, 0, (size_t)nb * 4, s));
       MMF_HIP(hipMemsetAsync(fb_fail_count, 0, 16, s));
       ScanProblem sp{};
       sp.X = X; sp.n = n; sp.Y = Y; sp.m = m; sp.d = d; sp.dtype = in_dtype; sp.metric = metric; sp.lambda = lambda;
+      sp.Xp = fb_Xp; sp.Yp = fb_Yp;
       sp.kk = kk; sp.rx = fo.rx; sp.cy = fo.cy; sp.row_ids = fail_rows + off; sp.n_rows = nb; sp.col_splits = fb_splits;
       MMF_TRY(launch_scan_f32(sp, FL, s, nullptr));
       SelectProblem fq = q;
@@ -354,6 +369,7 @@ struct FastTail {
         set_error("simtopk: %u rows failed in the exact rescan (internal invariant)", h_fb);
         return MMF_E_INTERNAL;
       }
+    }
     }
     MMF_TRY(t_fb.stop(s));
     if (stats) {
@@ -392,17 +408,19 @@ const char* mmf_last_error(void) { return g_err; }
 
 int mmf_release_workspaces(void) {
   std::lock_guard<std::mutex> lk(g_ws_mu);
-  for (auto& kv : g_ws) {
-    if (kv.second.base) {
-      int prev = -1;
-      (void)hipGetDevice(&prev);
-      (void)hipSetDevice(kv.first.first);
-      (void)hipDeviceSynchronize();
-      (void)hipFree(kv.second.base);
-      if (prev >= 0) (void)hipSetDevice(prev);
+  for (auto& slot : g_ws) {
+    for (auto& kv : slot) {
+      if (kv.second.base) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(kv.first.first);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(kv.second.base);
+        if (prev >= 0) (void)hipSetDevice(prev);
+      }
     }
+    slot.clear();
   }
-  g_ws.clear();
   return MMF_OK;
 }
 
@@ -516,7 +534,8 @@ int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d
   const int lists = 2 * splits;
   const bool same = (Y == X) && (m == n);
   size_t need = ws_bytes(n, 4) + (same ? 0 : ws_bytes(m, 4)) + ws_bytes((size_t)n * lists, 4) +
-                ws_bytes((size_t)n * lists * cap, 4) + ws_bytes(n, 4) + ws_bytes(n, 4) + ws_bytes(4, 4) + ws_bytes(256, 4);
+                ws_bytes((size_t)n * lists * cap, 4) + ws_bytes(n, 4) + ws_bytes(n, 4) + ws_bytes(4, 4) + ws_bytes(256, 4) +
+                ws_bytes(prep_f32_bytes(m, d), 1) + (same ? 0 : ws_bytes(prep_f32_bytes(n, d), 1));
   Workspace ws;
   MMF_TRY(get_workspace(device_id, s, need, &ws));
   float* rx = ws.take<float>(n);
@@ -538,10 +557,16 @@ int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d
   MMF_TRY(t_prep.start(profile, s));
   MMF_TRY(launch_row_scalars(X, n, d, in_dtype, metric, rx, nullptr, s));
   if (!same) MMF_TRY(launch_row_scalars(Y, m, d, in_dtype, metric, cy, nullptr, s));
+  // f32 operand images (mmf_prep.hip): what the exact scan's LDS-DMA copies
+  float* Yp = reinterpret_cast<float*>(ws.take<char>(prep_f32_bytes(m, d)));
+  float* Xp = same ? Yp : reinterpret_cast<float*>(ws.take<char>(prep_f32_bytes(n, d)));
+  MMF_TRY(launch_prep_f32(Y, m, d, in_dtype, nullptr, Yp, s));
+  if (!same) MMF_TRY(launch_prep_f32(X, n, d, in_dtype, nullptr, Xp, s));
   MMF_TRY(t_prep.stop(s));
 
   ScanProblem sp{};
   sp.X = X; sp.n = n; sp.Y = Y; sp.m = m; sp.d = d; sp.dtype = in_dtype; sp.metric = metric; sp.lambda = lambda;
+  sp.Xp = Xp; sp.Yp = Yp;
   sp.kk = kk; sp.rx = rx; sp.cy = cy; sp.row_ids = nullptr; sp.n_rows = n; sp.col_splits = splits;
   int grid = 0;
   MMF_TRY(t_scan.start(profile, s));
@@ -752,16 +777,24 @@ int mmf_sim_dense(const void* X, int64_t n, const void* Y, int64_t m, int64_t d,
   DeviceGuard guard(device_id);
   if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
   const bool same = (Y == X) && (m == n);
-  float *rx = nullptr, *cy = nullptr;
+  float *rx = nullptr, *cy = nullptr, *Xp = nullptr, *Yp = nullptr;
   if (metric != MMF_RBF_DIRECT) {
+    const bool img = sim_dense_needs_images(d, metric);
     Workspace ws;
-    MMF_TRY(get_workspace(device_id, s, ws_bytes(n, 4) + ws_bytes(m, 4), &ws));
+    MMF_TRY(get_workspace(device_id, s, ws_bytes(n, 4) + ws_bytes(m, 4) +
+                          (img ? ws_bytes(prep_f32_bytes(m, d), 1) + (same ? 0 : ws_bytes(prep_f32_bytes(n, d), 1)) : 0), &ws));
     rx = ws.take<float>(n);
     cy = same ? rx : ws.take<float>(m);
     MMF_TRY(launch_row_scalars(X, n, d, in_dtype, metric, rx, nullptr, s));
     if (!same) MMF_TRY(launch_row_scalars(Y, m, d, in_dtype, metric, cy, nullptr, s));
+    if (img) {
+      Yp = reinterpret_cast<float*>(ws.take<char>(prep_f32_bytes(m, d)));
+      Xp = same ? Yp : reinterpret_cast<float*>(ws.take<char>(prep_f32_bytes(n, d)));
+      MMF_TRY(launch_prep_f32(Y, m, d, in_dtype, nullptr, Yp, s));
+      if (!same) MMF_TRY(launch_prep_f32(X, n, d, in_dtype, nullptr, Xp, s));
+    }
   }
-  return launch_sim_dense(X, n, Y, m, d, in_dtype, metric, lambda, rx, cy, out, s);
+  return launch_sim_dense(X, n, Y, m, d, in_dtype, metric, lambda, rx, cy, Xp, Yp, out, s);
 }
 
 int mmf_sim_dense_stats(const void* X, int64_t n, const void* Y, int64_t m, int64_t d, int in_dtype, int metric, float lambda,
@@ -830,10 +863,12 @@ int mmf_sim_dense_combined(const float* F, const float* P, int64_t n, int64_t d,
   DeviceGuard guard(device_id);
   if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
   Workspace ws;
-  MMF_TRY(get_workspace(device_id, s, ws_bytes(n, 4), &ws));
+  MMF_TRY(get_workspace(device_id, s, ws_bytes(n, 4) + ws_bytes(prep_f32_bytes(n, d), 1), &ws));
   float* nf = ws.take<float>(n);
+  float* Fp = reinterpret_cast<float*>(ws.take<char>(prep_f32_bytes(n, d)));
   MMF_TRY(launch_row_scalars(F, n, d, MMF_F32, MMF_RBF, nf, nullptr, s));
-  return launch_sim_dense_combined(F, P, n, d, dp, lambda_h, lambda_g, nf, 0, n, out, s);
+  MMF_TRY(launch_prep_f32(F, n, d, MMF_F32, nullptr, Fp, s));
+  return launch_sim_dense_combined(Fp, P, n, d, dp, lambda_h, lambda_g, nf, 0, n, out, s);
 }
 
 int mmf_offdiag_lower_median(const float* K, int64_t n, float* out_median, int device_id, void* hip_stream) {
@@ -987,16 +1022,19 @@ int mmf_combined_offdiag_median(const float* F, const float* P, int64_t n, int64
   if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
   const int64_t R = pick_panel_rows(n, panel_rows);
   Workspace ws;
-  MMF_TRY(get_workspace(device_id, s, ws_bytes(n, 4) + ws_bytes((size_t)R * n, 4) + ws_bytes(median_state_bytes(), 1), &ws));
+  MMF_TRY(get_workspace(device_id, s, ws_bytes(n, 4) + ws_bytes((size_t)R * n, 4) + ws_bytes(median_state_bytes(), 1) +
+                        ws_bytes(prep_f32_bytes(n, d), 1), &ws));
   float* nf = ws.take<float>(n);
   float* Kp = ws.take<float>((size_t)R * n);
   void* st = ws.take<char>(median_state_bytes());
+  float* Fp = reinterpret_cast<float*>(ws.take<char>(prep_f32_bytes(n, d)));
   MMF_TRY(launch_row_scalars(F, n, d, MMF_F32, MMF_RBF, nf, nullptr, s));
+  MMF_TRY(launch_prep_f32(F, n, d, MMF_F32, nullptr, Fp, s));
   MMF_TRY(launch_median_begin(st, n, s));
   for (int pass = 0; pass < 4; ++pass) {             // one sweep over the recomputed matrix per radix byte
     for (int64_t r0 = 0; r0 < n; r0 += R) {
       const int64_t rows = (n - r0 < R) ? (n - r0) : R;
-      MMF_TRY(launch_sim_dense_combined(F, P, n, d, dp, lambda_h, lambda_g, nf, r0, rows, Kp, s));
+      MMF_TRY(launch_sim_dense_combined(Fp, P, n, d, dp, lambda_h, lambda_g, nf, r0, rows, Kp, s));
       MMF_TRY(launch_median_accumulate(Kp, n, r0, rows, st, pass, s));
     }
     MMF_TRY(launch_median_next(st, pass, out_median, s));
@@ -1019,14 +1057,17 @@ int mmf_combined_threshold_edges(const float* F, const float* P, int64_t n, int6
   const int64_t R = pick_panel_rows(n, panel_rows);
   const size_t rows_u32 = (size_t)R * 2 + 64;
   Workspace ws;
-  MMF_TRY(get_workspace(device_id, s, ws_bytes(n, 4) + ws_bytes((size_t)R * n, 4) + ws_bytes(rows_u32, 8), &ws));
+  MMF_TRY(get_workspace(device_id, s, ws_bytes(n, 4) + ws_bytes((size_t)R * n, 4) + ws_bytes(rows_u32, 8) +
+                        ws_bytes(prep_f32_bytes(n, d), 1), &ws));
   float* nf = ws.take<float>(n);
   float* Kp = ws.take<float>((size_t)R * n);
   uint32_t* scratch = reinterpret_cast<uint32_t*>(ws.take<uint64_t>(rows_u32));
+  float* Fp = reinterpret_cast<float*>(ws.take<char>(prep_f32_bytes(n, d)));
   MMF_TRY(launch_row_scalars(F, n, d, MMF_F32, MMF_RBF, nf, nullptr, s));
+  MMF_TRY(launch_prep_f32(F, n, d, MMF_F32, nullptr, Fp, s));
   for (int64_t r0 = 0; r0 < n; r0 += R) {            // panels in row order: the running count keeps the edges row-major
     const int64_t rows = (n - r0 < R) ? (n - r0) : R;
-    MMF_TRY(launch_sim_dense_combined(F, P, n, d, dp, lambda_h, lambda_g, nf, r0, rows, Kp, s));
+    MMF_TRY(launch_sim_dense_combined(Fp, P, n, d, dp, lambda_h, lambda_g, nf, r0, rows, Kp, s));
     MMF_TRY(launch_threshold_edges_panel(Kp, n, r0, rows, threshold, edge_index, edge_index ? edge_index + capacity : nullptr,
                                          edge_w, capacity, out_count, scratch, rows_u32 * 2, s));
   }

@@ -108,9 +108,18 @@ struct ScanB16Panel {
   int share = 0;                                       // more than one workgroup / launch scans each query
 };
 
+// mmf_prep.hip: the f32 operand image of mmf_scan_f32.hip — [prep_f32_rows(n)][prep_f32_dim(d)] floats, zero padded,
+// de-interleaved inside every group of eight k (k0 k2 k4 k6 | k1 k3 k5 k7).  row_ids: optional gather of the rows.
+int64_t prep_f32_rows(int64_t n);
+int64_t prep_f32_dim(int64_t d);
+size_t prep_f32_bytes(int64_t n, int64_t d);
+int launch_prep_f32(const void* X, int64_t n, int64_t d, int dtype, const int32_t* row_ids, float* out, hipStream_t s);
+
 struct ScanProblem {
   const void* X; int64_t n;       // query rows
   const void* Y; int64_t m;       // candidate rows (columns of the similarity matrix)
+  const float* Xp = nullptr;      // f32 images (launch_prep_f32) of the rows to scan — gathered when row_ids is set —
+  const float* Yp = nullptr;      //   and of the candidate rows: what the exact scan reads
   int64_t d;
   int dtype;
   int metric;
@@ -147,11 +156,13 @@ int launch_edge_cosine(const void* X, int64_t n, int64_t d, int dtype, const int
                        float* out, hipStream_t s);
 
 // mmf_dense.hip
+// Xp / Yp: f32 images of X and Y (launch_prep_f32; unused — may be null — for d <= 8 and MMF_RBF_DIRECT)
+bool sim_dense_needs_images(int64_t d, int metric);
 int launch_sim_dense(const void* X, int64_t n, const void* Y, int64_t m, int64_t d, int dtype,
-                     int metric, float lambda, const float* rx, const float* cy, float* out,
-                     hipStream_t s);
-// rows [row0, row0 + rows) of the combined n x n similarity; out [rows, n]
-int launch_sim_dense_combined(const float* F, const float* P, int64_t n, int64_t d, int64_t dp,
+                     int metric, float lambda, const float* rx, const float* cy, const float* Xp, const float* Yp,
+                     float* out, hipStream_t s);
+// rows [row0, row0 + rows) of the combined n x n similarity; out [rows, n].  Fp: f32 image of all n rows of F.
+int launch_sim_dense_combined(const float* Fp, const float* P, int64_t n, int64_t d, int64_t dp,
                               float lambda_h, float lambda_g, const float* nf, int64_t row0, int64_t rows, float* out,
                               hipStream_t s);
 

@@ -132,4 +132,72 @@ int launch_row_scalars(const void* X, int64_t n, int64_t d, int dtype, int metri
   return MMF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The f32 operand image of the exact scan and the dense outputs (mmf_scan_f32.hip): rows converted to f32, padded with
+// zero rows to a multiple of 128 and with zero columns to a multiple of 32, and DE-INTERLEAVED inside every group of
+// eight k — k0 k2 k4 k6 | k1 k3 k5 k7 — so that a 16-byte unit holds what ONE lane half of v_mfma_f32_32x32x2_f32
+// feeds to four consecutive k-steps.  The scan's LDS-DMA then copies units as they are and its chain reads one
+// ds_read_b128 per operand per four k-steps (zero padding: fmaf(0, 0, acc) = acc, the chain's bits do not change).
+// row_ids (optional): image row r is row row_ids[r] of X — the flagged rows of a rescan, gathered.
+__global__ __launch_bounds__(256) void prep_f32_kernel(const void* __restrict__ X, int64_t n, int64_t d, int dtype,
+                                                       const int32_t* __restrict__ row_ids, float* __restrict__ out,
+                                                       int64_t rows_pad, int64_t dpad, int vec) {
+  const int64_t gpr = dpad >> 3;                                   // groups of eight per image row
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= rows_pad * gpr) return;
+  const int64_t r = g / gpr, k0 = (g - r * gpr) * 8;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = 0.0f;
+  if (r < n) {
+    const int64_t src = row_ids ? (int64_t)row_ids[r] : r;
+    if (vec && k0 + 8 <= d) {
+      if (dtype == MMF_F32) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(X) + src * d + k0);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(X) + src * d + k0 + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+      } else {
+        const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(X) + src * d + k0);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint16_t lo = (uint16_t)(w[i] & 0xffffu), hi = (uint16_t)(w[i] >> 16);
+          if (dtype == MMF_BF16) { v[2 * i] = bf16_bits_to_f32(lo); v[2 * i + 1] = bf16_bits_to_f32(hi); }
+          else {
+            _Float16 hl, hh;
+            __builtin_memcpy(&hl, &lo, 2); __builtin_memcpy(&hh, &hi, 2);
+            v[2 * i] = (float)hl; v[2 * i + 1] = (float)hh;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (k0 + i < d) v[i] = ld_elem(X, src * d + k0 + i, dtype);
+    }
+  }
+  float* o = out + r * dpad + k0;
+  *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[2], v[4], v[6]};
+  *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[1], v[3], v[5], v[7]};
+}
+
+int64_t prep_f32_rows(int64_t n) { return (n + 127) / 128 * 128; }
+int64_t prep_f32_dim(int64_t d) { return (d + 31) / 32 * 32; }
+// + one block of 128 rows that is never written: a query tile of a launch whose first row is not a multiple of 128
+// (panel forms) reads up to 127 rows past the image; they only reach masked outputs, but must be mapped
+size_t prep_f32_bytes(int64_t n, int64_t d) { return (size_t)(prep_f32_rows(n) + 128) * (size_t)prep_f32_dim(d) * sizeof(float); }
+
+int launch_prep_f32(const void* X, int64_t n, int64_t d, int dtype, const int32_t* row_ids, float* out, hipStream_t s) {
+  if (n <= 0) return MMF_OK;
+  const int64_t rows_pad = prep_f32_rows(n), dpad = prep_f32_dim(d);
+  const int64_t groups = rows_pad * (dpad >> 3);
+  // 32-byte (f32) / 16-byte (16-bit) loads need d % 8 == 0 and an aligned base
+  const int vec = ((d & 7) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) ? 1 : 0;
+  hipLaunchKernelGGL(prep_f32_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, X, n, d, dtype, row_ids, out,
+                     rows_pad, dpad, vec);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+
 }  // namespace mmf

@@ -8,13 +8,23 @@
 // fmaf chain of include/mmf_hg.h (cdna_hip_programming.md §3 "FP32-input MFMA"), so the keys formed
 // here ARE the canonical keys: lists are truncated by the final total order and cannot overflow.
 //
-// Tiling: workgroup = 4 waves = 128 queries x 128 candidates per macro tile, K staged through LDS in
-// chunks of 32 (double buffered, one barrier per chunk).  Wave w owns queries 32w..32w+31 as the MFMA
-// column (B operand) and sweeps the 4 candidate sub-tiles as MFMA rows (A operand), so every lane
-// keeps ONE query and its candidate list is lane-private (mmf_dev.h).
-// LDS rows are padded to KC + 1 floats: lanes 0..31 of a ds_read_b32 hit 32 distinct banks.  (An 8-byte image —
-// k0 k2 | k1 k3 inside every group of four, one ds_read_b64 per operand per two k-steps, ds_write_b64 staging —
-// halves the LDS instructions and measured 6 % SLOWER in a same-process A/B, round 2: the 4-byte image stays.)
+// Tiling: workgroup = 4 waves = 128 queries x 128 candidates per macro tile, K staged through LDS in chunks of
+// 16 (scan) / 32 (dense), double buffered, one barrier per chunk.  Wave w owns queries 32w..32w+31 as the MFMA
+// column (B operand) and sweeps the 4 candidate sub-tiles as MFMA rows (A operand), so every lane keeps ONE query
+// and its candidate list is lane-private (mmf_dev.h).
+//
+// Operands come from the f32 IMAGES of X and Y (mmf_prep.hip: f32, zero padded to 128 rows / 32 columns, and inside
+// every group of eight k de-interleaved to k0 k2 k4 k6 | k1 k3 k5 k7).  A 16-byte unit of the image is what one lane
+// half of the MFMA feeds to four consecutive k-steps, so
+//   * staging is LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction, 4 or 8 per wave and chunk): no
+//     staging registers, no ds_write, no per-chunk address arithmetic (a loop-invariant lane offset + a scalar k offset);
+//   * the chain reads ONE ds_read_b128 per operand per four k-steps (5 per 16 MFMAs), the next group's while the
+//     current one multiplies.  LDS rows are KC floats, 16-byte units XOR-swizzled by row so that the 16 lanes of a
+//     b128 access group hit 16 distinct bank quads.
+// Round 2 measured the pieces in a bare loop (scripts/probe/f32_loop.hip, 2 workgroups per CU, of 157.3 TFLOP/s):
+// register loop 0.98, + ds_read_b32 operands 0.95, + barrier 0.95, + staging through registers and ds_write_b32 (the
+// round-1 kernel) 0.76, 16-byte [row][k] units with a per-half v_cndmask select 0.81 (VALU between the MFMAs is what
+// costs), de-interleaved image + LDS-DMA + b128 reads 0.91.
 //
 // Replaces: torch.mm + 3 elementwise passes, build_hypergraph/similarity_kernel.py:43-52, 79-84, 122;
 //           sklearn brute-force kneighbors, build_hypergraph/preprocess_hypergraph.py:379-382.
@@ -28,17 +38,16 @@ namespace mmf {
 constexpr int F_NT = 256;
 constexpr int F_QT = 128;
 constexpr int F_CT = 128;
-// k per staged chunk (template parameter KC, row stride KC + 1 floats): 16 for the scan — 2 x (128 + 128) rows x 17
-// floats = 35 KB beside 32 KB of lists, so two workgroups share a CU — and 32 for the dense outputs (no lists: two
-// workgroups fit anyway, and half the barriers measure 7 % faster).
+// k per staged chunk (template parameter KC): 16 for the scan — 2 x (128 + 128) rows x 64 B = 32 KB beside 32 KB of
+// lists, so two workgroups share a CU — and 32 for the dense outputs (no lists: two workgroups fit anyway, and half
+// the barriers measure 7 % faster).
 
 constexpr int MODE_SCAN = 0;
 constexpr int MODE_DENSE = 1;
 
 struct ScanF32Args {
-  const void* X; const void* Y;
-  int64_t n, m, d;
-  int dtype;
+  const float* Xp; const float* Yp;     // f32 images: row q of Xp is query position q of this launch
+  int64_t n, m, dpad;
   const float* rx; const float* cy;
   const int32_t* row_ids; int64_t n_rows;
   float neg_lambda;
@@ -54,35 +63,24 @@ struct ScanF32Args {
   int debug;   // MMF_F32_DEBUG (timing-only ablations): 1 skip epilogue, 2 skip staging
 };
 
-template <bool VEC4>
-__device__ __forceinline__ f32x4 load4(const void* base, int64_t row, int64_t k, int64_t d, int dtype) {
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (VEC4) {
-    if (k < d) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + row * d + k);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (k + i < d) v[i] = ld_elem(base, row * d + k + i, dtype);
-  }
-  return v;
-}
-
-template <int MODE, int CAP, bool VEC4, int F_KC>
+template <int MODE, int CAP, int F_KC>
 __global__ __launch_bounds__(F_NT, (MODE == MODE_DENSE || CAP <= 16) ? 2 : 1) void scan_f32_kernel(ScanF32Args a) {
-  constexpr int F_LD = F_KC + 1;
-  constexpr int TPR = F_KC / 4;          // staging: threads per row (16 bytes each)
-  constexpr int RPP = F_NT / TPR;        //          rows per pass
-  constexpr int NP = F_QT / RPP;         //          passes per 128-row tile
+  constexpr int UPR = F_KC / 4;            // 16-byte units per image row
+  constexpr int RPP = 64 / UPR;            // image rows per 1 KiB DMA piece
+  constexpr int HP = F_QT / RPP;           // pieces per operand tile (8 / 16)
+  constexpr int PPW = 2 * HP / 4;          // pieces per wave: the first half of them query pieces, the rest candidate pieces
+  constexpr int FSH = (UPR == 4) ? 2 : 1;  // unit u of row r sits at unit u ^ ((r >> FSH) & (UPR - 1))
+  constexpr int NG = F_KC / 8;             // groups of eight k per chunk
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* Qs = reinterpret_cast<float*>(smem);   // [2][F_QT][F_LD]
-  float* Cs = Qs + 2 * F_QT * F_LD;             // [2][F_CT][F_LD]
-  float* cys = Cs + 2 * F_CT * F_LD;            // [2][F_CT] per-candidate scalars of the tile being accumulated
+  float* Qs = reinterpret_cast<float*>(smem);   // [2][F_QT][F_KC]
+  float* Cs = Qs + 2 * F_QT * F_KC;             // [2][F_CT][F_KC]
+  float* cys = Cs + 2 * F_CT * F_KC;            // [2][F_CT] per-candidate scalars of the tile being accumulated
   float* lkeys = cys + 2 * F_CT;                // [CAP][F_NT]
   uint32_t* lids = reinterpret_cast<uint32_t*>(lkeys + CAP * F_NT);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5;
   const int c = lane & 31;
 
@@ -95,7 +93,7 @@ __global__ __launch_bounds__(F_NT, (MODE == MODE_DENSE || CAP <= 16) ? 2 : 1) vo
   int64_t t_end = t_begin + a.tiles_per_split;
   if (t_end > total_tiles) t_end = total_tiles;
   if (t_begin > t_end) t_begin = t_end;
-  const int nkc = (int)((a.d + F_KC - 1) / F_KC);
+  const int nkc = (int)(a.dpad / F_KC);
   const int64_t steps = (t_end - t_begin) * nkc;
 
   // this lane's query
@@ -121,59 +119,39 @@ __global__ __launch_bounds__(F_NT, (MODE == MODE_DENSE || CAP <= 16) ? 2 : 1) vo
     if (!qvalid) list.thr = __builtin_huge_valf();
   }
 
-  // staging roles: rows (tid / TPR) + RPP*i, k offset 4*(tid % TPR)
-  const int srow = tid / TPR;
-  const int sk = 4 * (tid % TPR);
-  int64_t qsrc[NP];
+  // DMA roles: piece p = wave + 4 i covers image rows [(p % HP) * RPP, + RPP) of the query (p < HP) or candidate tile;
+  // lane l lands at unit l of the piece = row l / UPR, unit l % UPR, and fetches the unit the swizzle puts there.
+  // The lane's byte offset inside a tile image is loop invariant; chunk and tile move through scalar offsets.
+  uint32_t voff[PPW];
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    int64_t p = q0 + srow + RPP * i;
-    if (p > a.n_rows - 1) p = a.n_rows - 1;
-    qsrc[i] = a.row_ids ? (int64_t)a.row_ids[p] : p;
+  for (int i = 0; i < PPW; ++i) {
+    const int row = ((wave + 4 * i) % HP) * RPP + lane / UPR;
+    const int lu = (lane % UPR) ^ ((row >> FSH) & (UPR - 1));
+    voff[i] = (uint32_t)(((int64_t)row * a.dpad + 4 * lu) * 4);
   }
-
-  f32x4 rq[NP], rc[NP];
+  const __amdgpu_buffer_rsrc_t qrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Xp + q0 * a.dpad), 0, -1, 0x00020000);
   float rcy = 0.0f;
-  auto gload = [&](int64_t step) {
-    const int64_t ct = t_begin + step / nkc;
-    const int64_t k = (int64_t)(step % nkc) * F_KC + sk;
-    if ((step % nkc) == 0 && tid < F_CT) {       // first chunk of a tile: its 128 per-candidate scalars ride along
+  // chunk kc of candidate tile ct -> stage `buf`; the tile's 128 per-candidate scalars ride along with its first chunk
+  auto stage = [&](int64_t ct, int kc, int buf) {
+    if (kc == 0 && tid < F_CT) {
       int64_t j = ct * F_CT + tid;
       if (j > a.m - 1) j = a.m - 1;
       rcy = a.cy[j];
     }
-    const int64_t kbase = (int64_t)(step % nkc) * F_KC;
-    if (VEC4 && kbase + F_KC <= a.d) {          // full chunk (wave-uniform): plain 16-byte loads, no predicates
-      const float* xf = reinterpret_cast<const float*>(a.X);
-      const float* yf = reinterpret_cast<const float*>(a.Y);
+    if (a.debug & 2) return;
+    const __amdgpu_buffer_rsrc_t crsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Yp + ct * F_CT * a.dpad), 0, -1, 0x00020000);
+    const int koff = kc * F_KC * 4;
 #pragma unroll
-      for (int i = 0; i < NP; ++i) {
-        rq[i] = *reinterpret_cast<const f32x4*>(xf + qsrc[i] * a.d + k);
-        int64_t j = ct * F_CT + srow + RPP * i;
-        if (j > a.m - 1) j = a.m - 1;
-        rc[i] = *reinterpret_cast<const f32x4*>(yf + j * a.d + k);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NP; ++i) {
-        rq[i] = load4<VEC4>(a.X, qsrc[i], k, a.d, a.dtype);
-        int64_t j = ct * F_CT + srow + RPP * i;
-        if (j > a.m - 1) j = a.m - 1;
-        rc[i] = load4<VEC4>(a.Y, j, k, a.d, a.dtype);
-      }
-    }
-  };
-  auto swrite = [&](int buf, int64_t step) {
-    if ((step % nkc) == 0 && tid < F_CT) cys[((step / nkc) & 1) * F_CT + tid] = rcy;
-    float* qd = Qs + buf * F_QT * F_LD + srow * F_LD + sk;
-    float* cd = Cs + buf * F_CT * F_LD + srow * F_LD + sk;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        qd[i * RPP * F_LD + e] = rq[i][e];
-        cd[i * RPP * F_LD + e] = rc[i][e];
-      }
+    for (int i = 0; i < PPW; ++i) {
+      const int pr = (wave + 4 * i) % HP;
+      if (i < PPW / 2)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(qrsrc, (__attribute__((address_space(3))) void*)(Qs + buf * F_QT * F_KC + pr * RPP * F_KC),
+                                                 16, (int)voff[i], koff, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, (__attribute__((address_space(3))) void*)(Cs + buf * F_CT * F_KC + pr * RPP * F_KC),
+                                                 16, (int)voff[i], koff, 0, 0);
     }
   };
 
@@ -183,49 +161,59 @@ __global__ __launch_bounds__(F_NT, (MODE == MODE_DENSE || CAP <= 16) ? 2 : 1) vo
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
+  // this lane's operand rows inside a stage: query row 32 wave + c, candidate rows c + 32 t (same swizzle for all t)
+  const int rqrow = 32 * wave + c;
+  const int fq = (rqrow >> FSH) & (UPR - 1), fc = (c >> FSH) & (UPR - 1);
+
   if (steps > 0) {
-    gload(0);
-    swrite(0, 0);
+    stage(t_begin, 0, 0);
+    if (tid < F_CT) cys[tid] = rcy;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  int64_t ct = t_begin;        // tile and chunk being multiplied
+  int kc = 0;
   for (int64_t s = 0; s < steps; ++s) {
     const int buf = (int)(s & 1);
-    if (s + 1 < steps && !(a.debug & 2)) gload(s + 1);
+    int nkcn = kc + 1;
+    int64_t nct = ct;
+    if (nkcn == nkc) { nkcn = 0; nct = ct + 1; }
+    if (s + 1 < steps) stage(nct, nkcn, buf ^ 1);
 
-    const float* Qb = Qs + buf * F_QT * F_LD + (32 * wave + c) * F_LD + half;
-    const float* Cb = Cs + buf * F_CT * F_LD + c * F_LD + half;
-    // operands of k-step k2+1 are read from LDS before the MFMAs of k-step k2 issue (one wave per SIMD:
-    // nothing else hides the LDS latency); the interleave is pinned for the scheduler
-    float bn = Qb[0];
-    float avn[4];
+    const float* Qrow = Qs + buf * F_QT * F_KC + rqrow * F_KC;
+    const float* Crow = Cs + buf * F_CT * F_KC + c * F_KC;
+    // operands of group g + 1 are read from LDS before the MFMAs of group g issue
+    f32x4 bn = *reinterpret_cast<const f32x4*>(Qrow + 4 * (half ^ fq));
+    f32x4 avn[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) avn[t] = Cb[t * 32 * F_LD];
+    for (int t = 0; t < 4; ++t) avn[t] = *reinterpret_cast<const f32x4*>(Crow + t * 32 * F_KC + 4 * (half ^ fc));
 #pragma unroll
-    for (int k2 = 0; k2 < F_KC / 2; ++k2) {
-      const float b = bn;
-      float av[4];
+    for (int g = 0; g < NG; ++g) {
+      const f32x4 b = bn;
+      f32x4 av[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) av[t] = avn[t];
-      if (k2 + 1 < F_KC / 2) {
-        bn = Qb[2 * (k2 + 1)];
+      if (g + 1 < NG) {
+        bn = *reinterpret_cast<const f32x4*>(Qrow + 4 * ((2 * (g + 1) + half) ^ fq));
 #pragma unroll
-        for (int t = 0; t < 4; ++t) avn[t] = Cb[t * 32 * F_LD + 2 * (k2 + 1)];
+        for (int t = 0; t < 4; ++t) avn[t] = *reinterpret_cast<const f32x4*>(Crow + t * 32 * F_KC + 4 * ((2 * (g + 1) + half) ^ fc));
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        // SCAN: C rows = candidates, columns = queries (a lane owns one query).  DENSE: the transpose — a lane owns
-        // one candidate COLUMN of the output, so the 32 lanes of a half store 128 contiguous bytes of one output
-        // row.  Products commute, the k order is the same: both orientations give the same bits.
-        if constexpr (MODE == MODE_DENSE) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, av[t], acc[t], 0, 0, 0);
-        else acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], b, acc[t], 0, 0, 0);
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          // SCAN: C rows = candidates, columns = queries (a lane owns one query).  DENSE: the transpose — a lane owns
+          // one candidate COLUMN of the output, so the 32 lanes of a half store 128 contiguous bytes of one output
+          // row.  Products commute, the k order is the same: both orientations give the same bits.
+          if constexpr (MODE == MODE_DENSE) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[e], av[t][e], acc[t], 0, 0, 0);
+          else acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][e], b[e], acc[t], 0, 0, 0);
+        }
       }
-      if (k2 + 1 < F_KC / 2) __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     }
 
-    if ((int)(s % nkc) == nkc - 1 && !(a.debug & 1)) {
-      const int64_t ct = t_begin + s / nkc;
+    if (kc == nkc - 1 && !(a.debug & 1)) {
+      const int tpar = (int)((ct - t_begin) & 1);
       // one 32 x 32 sub-tile at a time (keeping all four key vectors live costs 64 VGPRs and pushes the
       // staging registers of the next chunk into AGPRs, i.e. a vmcnt(0) in front of the MFMA block)
       if constexpr (MODE == MODE_DENSE) {
@@ -233,7 +221,7 @@ __global__ __launch_bounds__(F_NT, (MODE == MODE_DENSE || CAP <= 16) ? 2 : 1) vo
         for (int t = 0; t < 4; ++t) {
           const int64_t j = ct * F_CT + 32 * t + c;            // this lane's output column
           const bool jv = j < a.m;
-          const float cj = cys[((s / nkc) & 1) * F_CT + 32 * t + c];
+          const float cj = cys[tpar * F_CT + 32 * t + c];
           const float nl = (metric == MMF_RBF) ? a.neg_lambda : -1.0f;  // (-1)*sq == -sq exactly
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -265,7 +253,7 @@ __global__ __launch_bounds__(F_NT, (MODE == MODE_DENSE || CAP <= 16) ? 2 : 1) vo
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int64_t cand0 = ct * F_CT + 32 * t;
-        const float* cyt = cys + ((s / nkc) & 1) * F_CT + 32 * t + 4 * half;
+        const float* cyt = cys + tpar * F_CT + 32 * t + 4 * half;
         f32x16 key;
         // keys in three wave-uniform flavours (no per-element switch): dot | dot/(r*c) | nl*((r+c)-2dot)
         if (metric == MMF_DOT) {
@@ -298,7 +286,9 @@ __global__ __launch_bounds__(F_NT, (MODE == MODE_DENSE || CAP <= 16) ? 2 : 1) vo
     }
 
       }
-    if (s + 1 < steps && !(a.debug & 2)) swrite(buf ^ 1, s + 1);
+    if (s + 1 < steps && nkcn == 0 && tid < F_CT) cys[(int)((nct - t_begin) & 1) * F_CT + tid] = rcy;
+    ct = nct; kc = nkcn;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the next chunk have landed
     __syncthreads();
   }
 
@@ -322,36 +312,32 @@ int scan_f32_cap(int kk) {
 }
 
 static size_t scan_f32_lds(int cap, int kc) {
-  return sizeof(float) * (2 * F_QT * (kc + 1) + 2 * F_CT * (kc + 1) + 2 * F_CT) + (size_t)cap * F_NT * 8;
+  return sizeof(float) * (2 * F_QT * kc + 2 * F_CT * kc + 2 * F_CT) + (size_t)cap * F_NT * 8;
 }
 
 template <int MODE, int CAP>
-static int launch_f32_t(const ScanF32Args& a, bool vec4, int64_t grid, hipStream_t s) {
+static int launch_f32_t(const ScanF32Args& a, int64_t grid, hipStream_t s) {
   if (a.metric < MMF_DOT || a.metric > MMF_RBF) {
     set_error("scan_f32: unsupported metric %d", a.metric);
     return MMF_E_INVALID;
   }
+  if (!a.Xp || !a.Yp || a.dpad <= 0 || (a.dpad & 31) != 0 || a.dpad > (int64_t(1) << 21)) {
+    set_error("scan_f32: missing f32 operand images (or padded dim %lld not a multiple of 32 below 2^21)", (long long)a.dpad);
+    return MMF_E_INTERNAL;
+  }
   constexpr int KC = (MODE == MODE_SCAN) ? 16 : 32;
   const size_t lds = scan_f32_lds(MODE == MODE_SCAN ? CAP : 0, KC);
-  auto go = [&](auto kern) -> int {
-    MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(F_NT), lds, s, a);
-    MMF_LAUNCH_CHECK();
-    return MMF_OK;
-  };
-  if (vec4) return go(scan_f32_kernel<MODE, CAP, true, KC>);
-  return go(scan_f32_kernel<MODE, CAP, false, KC>);
-}
-
-static bool can_vec4(const void* X, const void* Y, int64_t d, int dtype) {
-  return dtype == MMF_F32 && (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
-         ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
+  auto kern = scan_f32_kernel<MODE, CAP, KC>;
+  MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(F_NT), lds, s, a);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
 }
 
 int launch_scan_f32(const ScanProblem& p, const CandLists& L, hipStream_t s, int* grid_out) {
   if (p.n_rows <= 0 || p.m <= 0) return MMF_OK;
   ScanF32Args a{};
-  a.X = p.X; a.Y = p.Y; a.n = p.n; a.m = p.m; a.d = p.d; a.dtype = p.dtype;
+  a.Xp = p.Xp; a.Yp = p.Yp; a.n = p.n; a.m = p.m; a.dpad = prep_f32_dim(p.d);
   a.rx = p.rx; a.cy = p.cy; a.row_ids = p.row_ids; a.n_rows = p.n_rows;
   a.neg_lambda = -p.lambda; a.kk = p.kk; a.col_splits = p.col_splits;
   const int64_t total_tiles = (p.m + F_CT - 1) / F_CT;
@@ -359,12 +345,11 @@ int launch_scan_f32(const ScanProblem& p, const CandLists& L, hipStream_t s, int
   a.cand_cnt = L.cnt; a.cand_ids = L.ids; a.overflow = L.overflow;
   const int64_t grid = ((p.n_rows + F_QT - 1) / F_QT) * p.col_splits;
   if (grid_out) *grid_out = (int)grid;
-  const bool v4 = can_vec4(p.X, p.Y, p.d, p.dtype);
   a.metric = p.metric;
   { const char* e = getenv("MMF_F32_DEBUG"); a.debug = e ? atoi(e) : 0; }
-  if (L.cap == 16) return launch_f32_t<MODE_SCAN, 16>(a, v4, grid, s);
-  if (L.cap == 32) return launch_f32_t<MODE_SCAN, 32>(a, v4, grid, s);
-  if (L.cap == 48) return launch_f32_t<MODE_SCAN, 48>(a, v4, grid, s);
+  if (L.cap == 16) return launch_f32_t<MODE_SCAN, 16>(a, grid, s);
+  if (L.cap == 32) return launch_f32_t<MODE_SCAN, 32>(a, grid, s);
+  if (L.cap == 48) return launch_f32_t<MODE_SCAN, 48>(a, grid, s);
   set_error("scan_f32: unsupported list capacity %d", L.cap);
   return MMF_E_INTERNAL;
 }
@@ -419,8 +404,11 @@ __global__ __launch_bounds__(256) void dense_small_d_kernel(const void* __restri
   }
 }
 
+bool sim_dense_needs_images(int64_t d, int metric) { return d > 8 && metric != MMF_RBF_DIRECT; }
+
 int launch_sim_dense(const void* X, int64_t n, const void* Y, int64_t m, int64_t d, int dtype, int metric,
-                     float lambda, const float* rx, const float* cy, float* out, hipStream_t s) {
+                     float lambda, const float* rx, const float* cy, const float* Xp, const float* Yp, float* out,
+                     hipStream_t s) {
   if (n <= 0 || m <= 0) return MMF_OK;
   if (d <= 8 && metric != MMF_RBF_DIRECT) {
     dim3 grid((unsigned)((m + 1023) / 1024), (unsigned)((n + 15) / 16));
@@ -430,7 +418,7 @@ int launch_sim_dense(const void* X, int64_t n, const void* Y, int64_t m, int64_t
   }
   if (metric == MMF_RBF_DIRECT) return launch_rbf_direct(X, n, Y, m, d, dtype, lambda, out, nullptr, nullptr, s);   // mmf_direct.hip
   ScanF32Args a{};
-  a.X = X; a.Y = Y; a.n = n; a.m = m; a.d = d; a.dtype = dtype;
+  a.Xp = Xp; a.Yp = Yp; a.n = n; a.m = m; a.dpad = prep_f32_dim(d);
   a.rx = rx; a.cy = cy; a.row_ids = nullptr; a.n_rows = n;
   a.neg_lambda = -lambda; a.kk = 0;
   const int64_t total_tiles = (m + F_CT - 1) / F_CT;
@@ -442,14 +430,16 @@ int launch_sim_dense(const void* X, int64_t n, const void* Y, int64_t m, int64_t
   a.tiles_per_split = (total_tiles + splits - 1) / splits;
   a.out = out;
   a.metric = metric;
-  return launch_f32_t<MODE_DENSE, 16>(a, can_vec4(X, Y, d, dtype), rbs * splits, s);
+  { const char* e = getenv("MMF_F32_DEBUG"); a.debug = e ? atoi(e) : 0; }
+  return launch_f32_t<MODE_DENSE, 16>(a, rbs * splits, s);
 }
 
-int launch_sim_dense_combined(const float* F, const float* P, int64_t n, int64_t d, int64_t dp, float lambda_h,
+int launch_sim_dense_combined(const float* Fp, const float* P, int64_t n, int64_t d, int64_t dp, float lambda_h,
                               float lambda_g, const float* nf, int64_t row0, int64_t rows, float* out, hipStream_t s) {
   if (n <= 0 || rows <= 0) return MMF_OK;
   ScanF32Args a{};
-  a.X = F + row0 * d; a.Y = F; a.n = rows; a.m = n; a.d = d; a.dtype = MMF_F32;
+  a.dpad = prep_f32_dim(d);
+  a.Xp = Fp + row0 * a.dpad; a.Yp = Fp; a.n = rows; a.m = n;
   a.rx = nf + row0; a.cy = nf; a.row_ids = nullptr; a.n_rows = rows;
   a.neg_lambda = -lambda_h; a.kk = 0;
   const int64_t total_tiles = (n + F_CT - 1) / F_CT;
@@ -460,7 +450,7 @@ int launch_sim_dense_combined(const float* F, const float* P, int64_t n, int64_t
   a.tiles_per_split = (total_tiles + splits - 1) / splits;
   a.out = out; a.P = P; a.dp = (int)dp; a.neg_lambda_g = -lambda_g; a.prow0 = row0;
   a.metric = MMF_RBF;
-  return launch_f32_t<MODE_DENSE, 16>(a, can_vec4(F, F, d, MMF_F32), rbs * splits, s);
+  return launch_f32_t<MODE_DENSE, 16>(a, rbs * splits, s);
 }
 
 }  // namespace mmf
