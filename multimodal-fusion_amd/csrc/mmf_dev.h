@@ -164,7 +164,9 @@ struct LaneList {
   // margin = 2e > 0 otherwise (keys are approximate: keep everything within the margin).
   template <bool EXACT>
   __device__ __forceinline__ void compact(int kk, float margin) {
-    if constexpr (CAP <= 16) compact_sorted<EXACT>(kk, margin);
+    // Final keys always rank by counting: the (key, id) sorting network of compact_pairs holds so many compare masks
+    // that the exact scan's hot loop paid for it in spilled scalar registers (1400 spills, v_readlane in every chunk).
+    if constexpr (CAP <= 16 && !EXACT) compact_sorted<EXACT>(kk, margin);
     else compact_ranked<EXACT>(kk, margin);
   }
 
