@@ -822,32 +822,41 @@ int mmf_sim_dense_stats(const void* X, int64_t n, const void* Y, int64_t m, int6
   }
   int64_t blocks = 0;
   for (int64_t r0 = 0; r0 < n; r0 += R) blocks += rbf_direct_blocks((n - r0 < R) ? (n - r0) : R, m);
+  const size_t mneed = median_scratch_bytes((unsigned long long)count);
   Workspace ws;
-  MMF_TRY(get_workspace(device_id, s, ws_bytes((size_t)blocks * stat_partial_bytes(), 1) + ws_bytes(64, 4) + ws_bytes(median_state_bytes(), 1) +
+  MMF_TRY(get_workspace(device_id, s, ws_bytes((size_t)blocks * stat_partial_bytes(), 1) + ws_bytes(64, 4) + ws_bytes(mneed, 1) +
                                       (out ? 0 : ws_bytes((size_t)R * m, 4)), &ws));
   char* part = ws.take<char>((size_t)blocks * stat_partial_bytes());
   float* pivot = ws.take<float>(64);
   float* med = pivot + 8;
-  void* mstate = ws.take<char>(median_state_bytes());
+  void* mscratch = ws.take<char>(mneed);
   MMF_TRY(launch_rbf_direct_pivot(X, Y, d, in_dtype, lambda, pivot, s));
   if (out) {
     MMF_TRY(launch_rbf_direct(X, n, Y, m, d, in_dtype, lambda, out, part, pivot, s));
-    MMF_TRY(launch_lower_median(out, count, med, mstate, s));
+    MMF_TRY(launch_lower_median(out, count, med, mscratch, s));
   } else {
+    // the matrix is never stored: every sweep of the median recomputes it panel by panel (one sweep when the sampled
+    // bracket holds, four radix passes otherwise); the first sweep also leaves the statistic partials
     float* panel = ws.take<float>((size_t)R * m);
-    MMF_TRY(launch_median_begin_count(mstate, (unsigned long long)count, s));
-    for (int pass = 0; pass < 4; ++pass) {
+    bool partials_done = false;
+    const MedianSweep sweep = [&](const MedianConsume& consume) -> int {
       int64_t b0 = 0;
       for (int64_t r0 = 0; r0 < n; r0 += R) {
         const int64_t rows = (n - r0 < R) ? (n - r0) : R;
-        const void* Xp = static_cast<const char*>(X) + (size_t)r0 * d * dtype_size(in_dtype);
-        MMF_TRY(launch_rbf_direct(Xp, rows, Y, m, d, in_dtype, lambda, panel,
-                                  pass == 0 ? part + (size_t)b0 * stat_partial_bytes() : nullptr, pivot, s));
-        MMF_TRY(launch_median_accumulate_flat(panel, m, rows, mstate, pass, s));
+        const void* Xr = static_cast<const char*>(X) + (size_t)r0 * d * dtype_size(in_dtype);
+        MMF_TRY(launch_rbf_direct(Xr, rows, Y, m, d, in_dtype, lambda, panel,
+                                  partials_done ? nullptr : part + (size_t)b0 * stat_partial_bytes(), pivot, s));
+        MMF_TRY(consume(panel, m, median_no_diagonal_row(), rows));
         b0 += rbf_direct_blocks(rows, m);
       }
-      MMF_TRY(launch_median_next(mstate, pass, med, s));
-    }
+      partials_done = true;
+      return MMF_OK;
+    };
+    MMF_TRY(lower_median_of((unsigned long long)count,
+                            [&](float* sample, int sc) {
+                              return launch_sample_pairs(X, Y, m, d, in_dtype, lambda, nullptr, 0, 0.0f, 0, (unsigned long long)count, sample, sc, s);
+                            },
+                            sweep, med, mscratch, s));
   }
   MMF_TRY(launch_stats_finish(part, blocks, pivot, count, out_stats, s));
   return launch_stats_set_median(med, out_stats, s);
@@ -878,9 +887,10 @@ int mmf_offdiag_lower_median(const float* K, int64_t n, float* out_median, int d
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   DeviceGuard guard(device_id);
   if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  const size_t need = median_scratch_bytes((unsigned long long)n * (unsigned long long)(n - 1));
   Workspace ws;
-  MMF_TRY(get_workspace(device_id, s, ws_bytes(4096, 4), &ws));
-  return launch_offdiag_lower_median(K, n, out_median, ws.take<uint32_t>(4096), s);
+  MMF_TRY(get_workspace(device_id, s, ws_bytes(need, 1), &ws));
+  return launch_offdiag_lower_median(K, n, out_median, ws.take<char>(need), s);
 }
 
 // ---- cluster-shaped steps (mmf_segments.hip) ----------------------------------------------------------------------
@@ -969,9 +979,10 @@ int mmf_lower_median(const float* v, int64_t count, float* out_median, int devic
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   DeviceGuard guard(device_id);
   if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  const size_t need = median_scratch_bytes((unsigned long long)count);
   Workspace ws;
-  MMF_TRY(get_workspace(device_id, s, ws_bytes(median_state_bytes(), 1), &ws));
-  return launch_lower_median(v, count, out_median, ws.take<char>(median_state_bytes()), s);
+  MMF_TRY(get_workspace(device_id, s, ws_bytes(need, 1), &ws));
+  return launch_lower_median(v, count, out_median, ws.take<char>(need), s);
 }
 
 int mmf_array_stats(const float* v, int64_t count, double* out_stats, int device_id, void* hip_stream) {
@@ -982,8 +993,8 @@ int mmf_array_stats(const float* v, int64_t count, double* out_stats, int device
   DeviceGuard guard(device_id);
   if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
   Workspace ws;
-  MMF_TRY(get_workspace(device_id, s, ws_bytes(array_stats_scratch_bytes(), 1), &ws));
-  return launch_array_stats(v, count, out_stats, ws.take<char>(array_stats_scratch_bytes()), s);
+  MMF_TRY(get_workspace(device_id, s, ws_bytes(array_stats_scratch_bytes(count), 1), &ws));
+  return launch_array_stats(v, count, out_stats, ws.take<char>(array_stats_scratch_bytes(count)), s);
 }
 
 int mmf_threshold_edges(const float* K, int64_t n, float threshold, int64_t* edge_index, float* edge_w,
@@ -1022,24 +1033,29 @@ int mmf_combined_offdiag_median(const float* F, const float* P, int64_t n, int64
   if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
   const int64_t R = pick_panel_rows(n, panel_rows);
   Workspace ws;
-  MMF_TRY(get_workspace(device_id, s, ws_bytes(n, 4) + ws_bytes((size_t)R * n, 4) + ws_bytes(median_state_bytes(), 1) +
+  const unsigned long long count = (unsigned long long)n * (unsigned long long)(n - 1);
+  const size_t mneed = median_scratch_bytes(count);
+  MMF_TRY(get_workspace(device_id, s, ws_bytes(n, 4) + ws_bytes((size_t)R * n, 4) + ws_bytes(mneed, 1) +
                         ws_bytes(prep_f32_bytes(n, d), 1), &ws));
   float* nf = ws.take<float>(n);
   float* Kp = ws.take<float>((size_t)R * n);
-  void* st = ws.take<char>(median_state_bytes());
+  void* mscratch = ws.take<char>(mneed);
   float* Fp = reinterpret_cast<float*>(ws.take<char>(prep_f32_bytes(n, d)));
   MMF_TRY(launch_row_scalars(F, n, d, MMF_F32, MMF_RBF, nf, nullptr, s));
   MMF_TRY(launch_prep_f32(F, n, d, MMF_F32, nullptr, Fp, s));
-  MMF_TRY(launch_median_begin(st, n, s));
-  for (int pass = 0; pass < 4; ++pass) {             // one sweep over the recomputed matrix per radix byte
-    for (int64_t r0 = 0; r0 < n; r0 += R) {
-      const int64_t rows = (n - r0 < R) ? (n - r0) : R;
-      MMF_TRY(launch_sim_dense_combined(Fp, P, n, d, dp, lambda_h, lambda_g, nf, r0, rows, Kp, s));
-      MMF_TRY(launch_median_accumulate(Kp, n, r0, rows, st, pass, s));
-    }
-    MMF_TRY(launch_median_next(st, pass, out_median, s));
-  }
-  return MMF_OK;
+  // one sweep over the recomputed matrix when the sampled bracket holds (four otherwise)
+  return lower_median_of(
+      count,
+      [&](float* sample, int sc) { return launch_sample_pairs(F, F, n, d, MMF_F32, lambda_h, P, (int)dp, lambda_g, 1, count, sample, sc, s); },
+      [&](const MedianConsume& consume) -> int {
+        for (int64_t r0 = 0; r0 < n; r0 += R) {
+          const int64_t rows = (n - r0 < R) ? (n - r0) : R;
+          MMF_TRY(launch_sim_dense_combined(Fp, P, n, d, dp, lambda_h, lambda_g, nf, r0, rows, Kp, s));
+          MMF_TRY(consume(Kp, n, r0, rows));
+        }
+        return MMF_OK;
+      },
+      out_median, mscratch, s);
 }
 
 int mmf_combined_threshold_edges(const float* F, const float* P, int64_t n, int64_t d, int64_t dp, float lambda_h,

@@ -20,15 +20,22 @@ __device__ __forceinline__ float ord2f(uint32_t o) {
   return __uint_as_float(u);
 }
 
-// state (u64 units): hist[256], then prefix (low 32 bits), then rank
+// a first-row index no column can reach: switches the diagonal skip off (flat arrays, rectangular panels)
+constexpr int64_t kNoDiagonal = -(int64_t(1) << 62);
+int64_t median_no_diagonal_row() { return kNoDiagonal; }
+
+// The histogram of a pass exists in 16 copies (a workgroup adds to copy blockIdx % 16): similarities are concentrated, so
+// every workgroup ends with the same one or two non-empty bins, and thousands of atomics on ONE address queue up at the
+// L2 (30 us per pass over 36 MB, measured); the pick sums the copies.
+constexpr int kHistCopies = 16;
 struct MedianState {
-  unsigned long long hist[256];
+  unsigned long long hist[kHistCopies][256];
   unsigned long long prefix;
   unsigned long long rank;
 };
 
-__global__ void median_init_kernel(MedianState* st, unsigned long long rank) {
-  if (threadIdx.x < 256) st->hist[threadIdx.x] = 0ull;
+__global__ __launch_bounds__(256) void median_init_kernel(MedianState* st, unsigned long long rank) {
+  for (int c = 0; c < kHistCopies; ++c) st->hist[c][threadIdx.x] = 0ull;
   if (threadIdx.x == 0) { st->prefix = 0ull; st->rank = rank; }
 }
 
@@ -72,34 +79,41 @@ __global__ __launch_bounds__(256) void median_hist_kernel(const float* __restric
   }
   if (run) atomicAdd(&lh[cur], run);
   __syncthreads();
-  if (lh[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+  if (lh[threadIdx.x]) atomicAdd(&st->hist[blockIdx.x % kHistCopies][threadIdx.x], (unsigned long long)lh[threadIdx.x]);
 }
 
-__global__ void median_pick_kernel(MedianState* st, int shift, float* out) {
-  if (threadIdx.x == 0) {
-    unsigned long long r = st->rank;
-    int b = 0;
-    for (; b < 255; ++b) {
-      const unsigned long long c = st->hist[b];
-      if (r < c) break;
-      r -= c;
-    }
-    st->rank = r;
-    st->prefix = st->prefix | ((unsigned long long)b << shift);
+// the bin that holds the wanted rank: 256 threads, inclusive scan of the histogram in LDS
+__global__ __launch_bounds__(256) void median_pick_kernel(MedianState* st, int shift, float* out) {
+  __shared__ unsigned long long cum[256];
+  const int t = threadIdx.x;
+  unsigned long long mine = 0ull;
+  for (int c = 0; c < kHistCopies; ++c) { mine += st->hist[c][t]; st->hist[c][t] = 0ull; }
+  cum[t] = mine;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const unsigned long long v = (t >= o) ? cum[t - o] : 0ull;
+    __syncthreads();
+    cum[t] += v;
+    __syncthreads();
+  }
+  const unsigned long long r = st->rank;
+  const unsigned long long before = cum[t] - mine;
+  // the first bin whose inclusive count exceeds the rank (bin 255 if none does: the serial loop's behaviour)
+  const bool here = (r >= before && r < cum[t]) || (t == 255 && r >= cum[255]);
+  __syncthreads();
+  if (here) {
+    st->rank = r - before;
+    st->prefix = st->prefix | ((unsigned long long)t << shift);
     if (shift == 0) *out = ord2f((uint32_t)st->prefix);
   }
-  __syncthreads();
-  if (threadIdx.x < 256) st->hist[threadIdx.x] = 0ull;
 }
 
-int launch_offdiag_lower_median(const float* K, int64_t n, float* out, uint32_t* scratch, hipStream_t s) {
-  MedianState* st = reinterpret_cast<MedianState*>(scratch);
-  MMF_TRY(launch_median_begin(st, n, s));
-  for (int pass = 0; pass < 4; ++pass) {
-    MMF_TRY(launch_median_accumulate(K, n, 0, n, st, pass, s));
-    MMF_TRY(launch_median_next(st, pass, out, s));
-  }
-  return MMF_OK;
+int launch_offdiag_lower_median(const float* K, int64_t n, float* out, void* scratch /* median_scratch_bytes(n (n - 1)) */,
+                                hipStream_t s) {
+  const unsigned long long count = (unsigned long long)n * (unsigned long long)(n - 1);
+  return lower_median_of(
+      count, [&](float* sample, int sc) { return launch_sample_gather(K, n, count, sample, sc, s); },
+      [&](const MedianConsume& consume) { return consume(K, n, 0, n); }, out, scratch, s);
 }
 
 // The same radix select in pieces, for matrices that are recomputed panel by panel instead of stored:
@@ -115,7 +129,7 @@ int launch_median_begin(void* state, int64_t n, hipStream_t s) {
 }
 int launch_median_accumulate(const float* K, int64_t n, int64_t row0, int64_t rows, void* state, int pass, hipStream_t s) {
   if (rows <= 0) return MMF_OK;
-  int64_t grid = rows < 4096 ? rows : 4096;          // workgroups take whole rows
+  int64_t grid = rows < 2048 ? rows : 2048;          // workgroups take whole rows (fewer workgroups: fewer same-address atomics at the end)
   hipLaunchKernelGGL(median_hist_kernel, dim3((unsigned)grid), dim3(256), 0, s, K, n, row0, rows,
                      reinterpret_cast<MedianState*>(state), 24 - 8 * pass);
   MMF_LAUNCH_CHECK();
@@ -127,20 +141,363 @@ int launch_median_next(void* state, int pass, float* out, hipStream_t s) {
   return MMF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Lower median in ONE sweep over the data (instead of four): a sampled bracket, verified by exact counts.
+//
+//  1. 32768 entries at hashed positions (uniform over the population, so its quantiles are unbiased whatever the
+//     row / column structure of the matrix) go through an in-LDS radix select that returns the sample's quantiles at
+//     0.5 -+ 1.66 % (six standard deviations of a sample quantile): the bracket [lo, hi].
+//  2. The sweep counts the entries below lo and appends the entries inside [lo, hi] (about 3.3 % of them) to a buffer:
+//     a wave compacts its hits through a private LDS stage (ballot ranks, no atomics) and reserves buffer space with one
+//     atomicAdd per ~800 entries.
+//  3. If  below <= rank < below + inside  (and the buffer held everything), the median is the entry of rank
+//     rank - below among the buffered values: a radix select over 3 % of the data.  The result is EXACT — the sample
+//     only chose where to look.  Otherwise (an unlucky bracket, or so many equal values that the buffer overflows) the
+//     caller falls back to the four-pass radix select; both give the same value.
+// The sweep reads the data once, so the matrices that are recomputed panel by panel (mmf_combined_offdiag_median,
+// mmf_sim_dense_stats without an output) are recomputed once instead of four times.
+// ------------------------------------------------------------------------------------------------
+constexpr int kBracketSample = 32768;
+constexpr int kBracketHalfWidth = 544;          // ranks either side of the sample's middle: 3 sqrt(32768)
+
+constexpr int kBracketSegs = 64;                 // the buffer is 64 segments with a cursor each: waves that reserve space do not
+constexpr int kBracketPad = 16;                  //   queue up on ONE address (cursors and below-counters sit 128 B apart)
+struct BracketState {
+  unsigned long long rank, seg_cap, inside, pad0;
+  float lo, hi;
+  uint32_t fail, pad;
+  MedianState sel;                               // radix select inside the buffer
+  unsigned long long cursor[kBracketSegs * kBracketPad];
+  unsigned long long below[kBracketSegs * kBracketPad];
+};
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {      // splitmix64 finaliser
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+// sample entry i of a stored array: flat (n_sq == 0: `count` values) or the off-diagonal of an n_sq x n_sq matrix
+__global__ __launch_bounds__(256) void sample_gather_kernel(const float* __restrict__ data, int64_t n_sq, unsigned long long count,
+                                                            int s, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= s) return;
+  const unsigned long long idx = mix64((unsigned long long)i) % count;
+  if (n_sq == 0) { out[i] = data[idx]; return; }
+  const unsigned long long r = idx / (unsigned long long)(n_sq - 1);
+  unsigned long long c = idx - r * (unsigned long long)(n_sq - 1);
+  c += (c >= r) ? 1ull : 0ull;
+  out[i] = data[r * (unsigned long long)n_sq + c];
+}
+
+// sample entry i of a matrix that is NOT stored: exp(-lambda |a_r - b_c|^2) [* exp(-lambda_g |p_r - p_c|^2)] of a hashed
+// pair, one wave per pair, lanes across k (not the canonical chain: the sample only places the bracket).
+// offdiag != 0: A == B, pairs (r, c) with r != c.
+__global__ __launch_bounds__(256) void sample_pairs_kernel(const void* __restrict__ A, const void* __restrict__ B, int64_t nb, int64_t d,
+                                                           int dtype, float neg_lambda, const float* __restrict__ P, int dp,
+                                                           float neg_lambda_g, int offdiag, unsigned long long count, int s,
+                                                           float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= s) return;
+  const unsigned long long idx = mix64((unsigned long long)i) % count;
+  const unsigned long long per = (unsigned long long)(offdiag ? nb - 1 : nb);
+  const unsigned long long r = idx / per;
+  unsigned long long c = idx - r * per;
+  if (offdiag) c += (c >= r) ? 1ull : 0ull;
+  float acc = 0.0f;
+  for (int64_t k = lane; k < d; k += 64) {
+    const float t = ld_elem(A, (int64_t)r * d + k, dtype) - ld_elem(B, (int64_t)c * d + k, dtype);
+    acc = __builtin_fmaf(t, t, acc);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) {
+    float v = expf(neg_lambda * acc);
+    if (P) {
+      float g = 0.0f;
+      for (int e = 0; e < dp; ++e) { const float t = P[r * dp + e] - P[c * dp + e]; g = __builtin_fmaf(t, t, g); }
+      v *= expf(neg_lambda_g * g);
+    }
+    out[i] = v;
+  }
+}
+
+// one workgroup: the sample's order statistics r_lo and r_hi by radix select out of LDS -> the bracket; state reset.
+// A thread owns every 1024th key and counts runs of equal bins in a register (similarities are concentrated: without
+// that the first passes are 32768 atomics on one LDS word).
+__global__ __launch_bounds__(1024) void bracket_bounds_kernel(const float* __restrict__ sample, int s, int r_lo, int r_hi,
+                                                              unsigned long long rank, unsigned long long seg_cap, BracketState* st) {
+  extern __shared__ uint32_t bkeys[];
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned int cum[256];
+  __shared__ uint32_t sh_prefix;
+  __shared__ int sh_rank;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < s; i += 1024) bkeys[i] = f2ord(sample[i]);
+  for (int i = tid; i < kBracketSegs * kBracketPad; i += 1024) { st->cursor[i] = 0ull; st->below[i] = 0ull; }
+  uint32_t found[2] = {0u, 0u};
+  for (int which = 0; which < 2; ++which) {
+    __syncthreads();
+    if (tid == 0) { sh_prefix = 0u; sh_rank = which ? r_hi : r_lo; }
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      if (tid < 256) hist[tid] = 0u;
+      __syncthreads();
+      const uint32_t prefix = sh_prefix;
+      const uint32_t himask = (shift == 24) ? 0u : (0xffffffffu << (shift + 8));
+      uint32_t cur = 0xffffffffu, run = 0u;
+      for (int i = tid; i < s; i += 1024) {        // interleaved ownership: conflict-free LDS reads
+        const uint32_t k = bkeys[i];
+        if ((k & himask) != (prefix & himask)) continue;
+        const uint32_t bin = (k >> shift) & 255u;
+        if (bin == cur) { ++run; continue; }
+        if (run) atomicAdd(&hist[cur], run);
+        cur = bin; run = 1u;
+      }
+      if (run) atomicAdd(&hist[cur], run);
+      __syncthreads();
+      if (tid < 256) cum[tid] = hist[tid];
+      __syncthreads();
+      for (int o = 1; o < 256; o <<= 1) {
+        unsigned int v = 0u;
+        if (tid < 256 && tid >= o) v = cum[tid - o];
+        __syncthreads();
+        if (tid < 256) cum[tid] += v;
+        __syncthreads();
+      }
+      if (tid < 256) {
+        const unsigned int r = (unsigned int)sh_rank, before = cum[tid] - hist[tid];
+        if ((r >= before && r < cum[tid]) || (tid == 255 && r >= cum[255])) {
+          sh_rank = (int)(r - before);
+          sh_prefix = prefix | ((uint32_t)tid << shift);
+        }
+      }
+      __syncthreads();
+    }
+    found[which] = sh_prefix;
+  }
+  if (tid == 0) {
+    st->lo = ord2f(found[0]); st->hi = ord2f(found[1]);
+    st->rank = rank; st->seg_cap = seg_cap; st->inside = 0ull; st->fail = 0u; st->pad = 0u;
+  }
+}
+
+// K: rows [row0, row0 + rows) of a matrix with n columns; the entry (row0 + li, j == row0 + li) is skipped (pass
+// kNoDiagonal as row0 for data without a diagonal).  One wave per row, 16 bytes per lane when n % 4 == 0.
+__global__ __launch_bounds__(256) void bracket_sweep_kernel(const float* __restrict__ K, int64_t n, int64_t row0, int64_t rows,
+                                                            BracketState* st, float* __restrict__ buf) {
+  __shared__ float stage[4][1024];
+  __shared__ unsigned long long wbelow[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float lo = st->lo, hi = st->hi;
+  const unsigned long long seg_cap = st->seg_cap;
+  const int seg = (int)((blockIdx.x * 4u + (unsigned)w) % (unsigned)kBracketSegs);
+  float* sbuf = buf + (size_t)seg * seg_cap;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  unsigned long long below = 0ull;
+  int cnt = 0;                                   // wave-uniform: entries waiting in this wave's stage
+  auto flush = [&]() {
+    unsigned long long base = 0ull;
+    if (lane == 0) base = atomicAdd(&st->cursor[seg * kBracketPad], (unsigned long long)cnt);
+    base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (unsigned long long)(uint32_t)__shfl((int)(uint32_t)base, 0);
+    for (int i = lane; i < cnt; i += 64)
+      if (base + (unsigned long long)i < seg_cap) sbuf[base + (unsigned long long)i] = stage[w][i];
+    cnt = 0;
+  };
+  auto offer = [&](float x, bool valid) {
+    const bool in = valid && x >= lo && x <= hi;
+    below += (valid && x < lo) ? 1ull : 0ull;
+    const unsigned long long mask = __ballot(in);
+    if (in) stage[w][cnt + __popcll(mask & lt)] = x;
+    cnt += __popcll(mask);
+  };
+  const bool vec = ((n & 3) == 0) && ((reinterpret_cast<uintptr_t>(K) & 15) == 0);
+  for (int64_t li = (int64_t)blockIdx.x * 4 + w; li < rows; li += (int64_t)gridDim.x * 4) {
+    const float* row = K + li * n;
+    const int64_t i = row0 + li;
+    if (vec) {
+      for (int64_t j0 = 0; j0 < n; j0 += 256) {          // wave-uniform trip count: the ballots see every lane
+        const int64_t j = j0 + (int64_t)lane * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (j < n) v = *reinterpret_cast<const f32x4*>(row + j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) offer(v[e], j < n && j + e != i);
+        if (cnt > 1024 - 256) flush();
+      }
+    } else {
+      for (int64_t j0 = 0; j0 < n; j0 += 64) {
+        const int64_t j = j0 + lane;
+        offer(j < n ? row[j] : 0.0f, j < n && j != i);
+        if (cnt > 1024 - 64) flush();
+      }
+    }
+  }
+  if (cnt > 0) flush();
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long hi32 = (unsigned long long)(uint32_t)__shfl_xor((int)(below >> 32), o);
+    const unsigned long long lo32 = (unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)below, o);
+    below += (hi32 << 32) | lo32;
+  }
+  if (lane == 0) wbelow[w] = below;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = wbelow[0] + wbelow[1] + wbelow[2] + wbelow[3];
+    if (t) atomicAdd(&st->below[(blockIdx.x % (unsigned)kBracketSegs) * kBracketPad], t);
+  }
+}
+
+// does the bracket hold the wanted rank?  sets up the select inside the buffer
+__global__ __launch_bounds__(64) void bracket_begin_kernel(BracketState* st) {
+  const int t = threadIdx.x;
+  unsigned long long c = st->cursor[t * kBracketPad], b = st->below[t * kBracketPad];
+  const bool over = c > st->seg_cap;
+  unsigned long long hi32, lo32;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    hi32 = (unsigned long long)(uint32_t)__shfl_xor((int)(c >> 32), o); lo32 = (unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)c, o);
+    c += (hi32 << 32) | lo32;
+    hi32 = (unsigned long long)(uint32_t)__shfl_xor((int)(b >> 32), o); lo32 = (unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)b, o);
+    b += (hi32 << 32) | lo32;
+  }
+  const bool any_over = __any(over);
+  for (int c = 0; c < kHistCopies; ++c)
+    for (int i = t; i < 256; i += 64) st->sel.hist[c][i] = 0ull;
+  if (t == 0) {
+    const bool ok = !any_over && st->rank >= b && (st->rank - b) < c;
+    st->fail = ok ? 0u : 1u;
+    st->inside = c;
+    st->sel.prefix = 0ull;
+    st->sel.rank = ok ? (st->rank - b) : 0ull;
+  }
+}
+
+// one radix pass over the buffered values: workgroup -> (segment, slice of it); runs of equal bins counted in a register
+__global__ __launch_bounds__(256) void bracket_hist_kernel(const float* __restrict__ buf, BracketState* st, int shift) {
+  __shared__ unsigned int lh[256];
+  lh[threadIdx.x] = 0u;
+  __syncthreads();
+  if (st->fail == 0u) {
+    const int seg = blockIdx.x % kBracketSegs, part = blockIdx.x / kBracketSegs, parts = gridDim.x / kBracketSegs;
+    const unsigned long long count = st->cursor[seg * kBracketPad];
+    const float* sbuf = buf + (size_t)seg * st->seg_cap;
+    const uint32_t prefix = (uint32_t)st->sel.prefix;
+    const uint32_t himask = (shift == 24) ? 0u : (0xffffffffu << (shift + 8));
+    uint32_t cur = 0xffffffffu, run = 0u;
+    for (unsigned long long i = (unsigned long long)part * 256 + threadIdx.x; i < count; i += (unsigned long long)parts * 256) {
+      const uint32_t o = f2ord(sbuf[i]);
+      if ((o & himask) != (prefix & himask)) continue;
+      const uint32_t bin = (o >> shift) & 255u;
+      if (bin == cur) { ++run; continue; }
+      if (run) atomicAdd(&lh[cur], run);
+      cur = bin; run = 1u;
+    }
+    if (run) atomicAdd(&lh[cur], run);
+  }
+  __syncthreads();
+  if (lh[threadIdx.x]) atomicAdd(&st->sel.hist[blockIdx.x % kHistCopies][threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+}
+
+__global__ void bracket_report_kernel(const BracketState* st, uint32_t* flag) { *flag = st->fail; }
+
+size_t bracket_state_bytes() { return (sizeof(BracketState) + 255) & ~size_t(255); }
+// buffer entries for a population of `count` (0: the one-sweep path is not used — small or enormous populations)
+unsigned long long bracket_capacity(unsigned long long count) {
+  if (getenv("MMF_MEDIAN_RADIX")) return 0ull;                   // A/B switch: always the four-pass select
+  if (count < (1ull << 22)) return 0ull;
+  unsigned long long cap = count / 20ull + 65536ull;             // 5 %: the bracket holds 3.3 % in expectation
+  cap = (cap + kBracketSegs * 64 - 1) / (kBracketSegs * 64) * (kBracketSegs * 64);   // 64 segments of whole 256-byte lines
+  if (cap * 4ull > (2ull << 30)) return 0ull;
+  return cap;
+}
+size_t median_scratch_bytes(unsigned long long count) {
+  return bracket_state_bytes() + kBracketSample * sizeof(float) + 256 + (size_t)bracket_capacity(count) * sizeof(float) + 256 +
+         ((sizeof(MedianState) + 255) & ~size_t(255));
+}
+
+// out (device): the lower median of `count` values — torch.median's element (count - 1) / 2.
+//   sampler(sample, s): fills s sample values (device);  sweep(consume): streams the whole population once through
+//   consume(data, cols, row0, rows) (row0: global row of the first row for the diagonal skip, or kNoDiagonalRow).
+// One host synchronisation (the bracket's verdict) when the one-sweep path is taken.
+int lower_median_of(unsigned long long count, const MedianSampler& sampler, const MedianSweep& sweep, float* out, void* scratch,
+                    hipStream_t s) {
+  char* base = static_cast<char*>(scratch);
+  BracketState* st = reinterpret_cast<BracketState*>(base);
+  float* sample = reinterpret_cast<float*>(base + bracket_state_bytes());
+  const unsigned long long cap = bracket_capacity(count);
+  float* buf = sample + kBracketSample + 64;
+  void* radix = reinterpret_cast<char*>(buf) + (((size_t)cap * sizeof(float) + 255) & ~size_t(255));
+  const unsigned long long rank = (count - 1ull) / 2ull;
+  if (cap != 0ull) {
+    MMF_TRY(sampler(sample, kBracketSample));
+    MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bracket_bounds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kBracketSample * 4));
+    hipLaunchKernelGGL(bracket_bounds_kernel, dim3(1), dim3(1024), kBracketSample * 4, s, sample, kBracketSample,
+                       kBracketSample / 2 - kBracketHalfWidth, kBracketSample / 2 + kBracketHalfWidth, rank, cap / kBracketSegs, st);
+    MMF_LAUNCH_CHECK();
+    MMF_TRY(sweep([&](const float* data, int64_t cols, int64_t row0, int64_t rows) -> int {
+      if (rows <= 0) return MMF_OK;
+      int64_t grid = (rows + 3) / 4;
+      if (grid > 2048) grid = 2048;
+      hipLaunchKernelGGL(bracket_sweep_kernel, dim3((unsigned)grid), dim3(256), 0, s, data, cols, row0, rows, st, buf);
+      MMF_LAUNCH_CHECK();
+      return MMF_OK;
+    }));
+    hipLaunchKernelGGL(bracket_begin_kernel, dim3(1), dim3(64), 0, s, st);
+    MMF_LAUNCH_CHECK();
+    MedianState* sel = &st->sel;
+    for (int pass = 0; pass < 4; ++pass) {
+      hipLaunchKernelGGL(bracket_hist_kernel, dim3(16 * kBracketSegs), dim3(256), 0, s, buf, st, 24 - 8 * pass);
+      MMF_LAUNCH_CHECK();
+      hipLaunchKernelGGL(median_pick_kernel, dim3(1), dim3(256), 0, s, sel, 24 - 8 * pass, out);
+      MMF_LAUNCH_CHECK();
+    }
+    uint32_t h_fail = 1;
+    MMF_HIP(hipMemcpyAsync(&h_fail, &st->fail, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    MMF_HIP(hipStreamSynchronize(s));
+    if (h_fail == 0u) return MMF_OK;
+  }
+  // four-pass radix select over the whole population
+  MMF_TRY(launch_median_begin_count(radix, count, s));
+  for (int pass = 0; pass < 4; ++pass) {
+    MMF_TRY(sweep([&](const float* data, int64_t cols, int64_t row0, int64_t rows) -> int {
+      return launch_median_accumulate(data, cols, row0, rows, radix, pass, s);
+    }));
+    MMF_TRY(launch_median_next(radix, pass, out, s));
+  }
+  return MMF_OK;
+}
+
+int launch_sample_gather(const float* data, int64_t n_sq, unsigned long long count, float* sample, int s_count, hipStream_t s) {
+  hipLaunchKernelGGL(sample_gather_kernel, dim3((unsigned)((s_count + 255) / 256)), dim3(256), 0, s, data, n_sq, count, s_count, sample);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+int launch_sample_pairs(const void* A, const void* B, int64_t nb, int64_t d, int dtype, float lambda, const float* P, int dp,
+                        float lambda_g, int offdiag, unsigned long long count, float* sample, int s_count, hipStream_t s) {
+  hipLaunchKernelGGL(sample_pairs_kernel, dim3((unsigned)((s_count + 3) / 4)), dim3(256), 0, s, A, B, nb, d, dtype, -lambda, P, dp,
+                     -lambda_g, offdiag, count, s_count, sample);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+
+// flat array as rows of 4096 values plus one ragged row
+static int sweep_flat(const float* v, int64_t count, const MedianConsume& consume) {
+  const int64_t C = 4096, full = count / C, tail = count - full * C;
+  if (full > 0) MMF_TRY(consume(v, C, kNoDiagonal, full));
+  if (tail > 0) MMF_TRY(consume(v + full * C, tail, kNoDiagonal, 1));
+  return MMF_OK;
+}
+
 // Lower median (torch.median semantics: element (count - 1) / 2 of the sorted values) of a flat array — the
 // similarity statistics of preprocess_hypergraph.py:190-196, 259-265 and the edge-weight median of :885-897.
 // The array is walked as rows of 4096 values (plus one ragged row) by the same histogram kernel; a row0 that no
 // column index can reach switches the diagonal skip off.
-constexpr int64_t kNoDiagonal = -(int64_t(1) << 62);
-int launch_lower_median(const float* v, int64_t count, float* out, void* state, hipStream_t s) {
-  MMF_TRY(launch_median_begin_count(state, (unsigned long long)count, s));
-  const int64_t C = 4096, full = count / C, tail = count - full * C;
-  for (int pass = 0; pass < 4; ++pass) {
-    if (full > 0) MMF_TRY(launch_median_accumulate(v, C, kNoDiagonal, full, state, pass, s));
-    if (tail > 0) MMF_TRY(launch_median_accumulate(v + full * C, tail, kNoDiagonal, 1, state, pass, s));
-    MMF_TRY(launch_median_next(state, pass, out, s));
-  }
-  return MMF_OK;
+int launch_lower_median(const float* v, int64_t count, float* out, void* scratch /* median_scratch_bytes(count) */, hipStream_t s) {
+  return lower_median_of(
+      (unsigned long long)count, [&](float* sample, int sc) { return launch_sample_gather(v, 0, (unsigned long long)count, sample, sc, s); },
+      [&](const MedianConsume& consume) { return sweep_flat(v, count, consume); }, out, scratch, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -215,20 +572,20 @@ __global__ __launch_bounds__(256) void stats_final_kernel(const float* __restric
 
 __global__ void stats_median_kernel(const float* med, double* out) { out[4] = (double)*med; }
 
-size_t array_stats_scratch_bytes() { return 2048 * sizeof(StatPartial) + sizeof(MedianState) + 256; }
+size_t array_stats_scratch_bytes(int64_t count) { return 2048 * sizeof(StatPartial) + 256 + median_scratch_bytes((unsigned long long)count); }
 
 int launch_array_stats(const float* v, int64_t count, double* out, void* scratch, hipStream_t s) {
   StatPartial* part = reinterpret_cast<StatPartial*>(scratch);
   char* rest = reinterpret_cast<char*>(scratch) + 2048 * sizeof(StatPartial);
   float* med = reinterpret_cast<float*>(rest);
-  void* mstate = rest + 256;
+  void* mscratch = rest + 256;
   int64_t grid = (count + 256 * 16 - 1) / (256 * 16);
   if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(stats_partial_kernel, dim3((unsigned)grid), dim3(256), 0, s, v, count, part);
   MMF_LAUNCH_CHECK();
   MMF_TRY(launch_stats_finish(part, grid, v, count, out, s));
-  MMF_TRY(launch_lower_median(v, count, med, mstate, s));
+  MMF_TRY(launch_lower_median(v, count, med, mscratch, s));
   return launch_stats_set_median(med, out, s);
 }
 

@@ -2,6 +2,7 @@
 // grow-only workspaces, launch checks, and the internal kernel-launcher prototypes.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <functional>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -167,7 +168,20 @@ int launch_sim_dense_combined(const float* Fp, const float* P, int64_t n, int64_
                               hipStream_t s);
 
 // mmf_edges.hip
-int launch_offdiag_lower_median(const float* K, int64_t n, float* out, uint32_t* scratch /*>=1024 u32*/,
+// Lower medians (torch.median: element (count - 1) / 2).  A population of 4 M values or more is first tried in ONE sweep
+// (sampled bracket, exact counts, select among the ~3 % inside the bracket; one host sync for the verdict); the four-pass
+// radix select is the fallback and the small-size path.  MMF_MEDIAN_RADIX=1 forces the latter.
+using MedianConsume = std::function<int(const float* data, int64_t cols, int64_t row0, int64_t rows)>;
+using MedianSweep = std::function<int(const MedianConsume&)>;      // streams the whole population once through `consume`
+using MedianSampler = std::function<int(float* sample, int s)>;   // s values at hashed positions (device)
+size_t median_scratch_bytes(unsigned long long count);
+int64_t median_no_diagonal_row();                                  // row0 for data without a diagonal to skip
+int lower_median_of(unsigned long long count, const MedianSampler& sampler, const MedianSweep& sweep, float* out, void* scratch,
+                    hipStream_t s);
+int launch_sample_gather(const float* data, int64_t n_sq, unsigned long long count, float* sample, int s_count, hipStream_t s);
+int launch_sample_pairs(const void* A, const void* B, int64_t nb, int64_t d, int dtype, float lambda, const float* P, int dp,
+                        float lambda_g, int offdiag, unsigned long long count, float* sample, int s_count, hipStream_t s);
+int launch_offdiag_lower_median(const float* K, int64_t n, float* out, void* scratch /* median_scratch_bytes(n (n - 1)) */,
                                 hipStream_t s);
 // the radix select in pieces (matrices recomputed panel by panel): begin; for pass 0..3 { accumulate panels; next }
 size_t median_state_bytes();
@@ -175,8 +189,8 @@ int launch_median_begin(void* state, int64_t n, hipStream_t s);
 int launch_median_accumulate(const float* K, int64_t n, int64_t row0, int64_t rows, void* state, int pass, hipStream_t s);
 int launch_median_next(void* state, int pass, float* out, hipStream_t s);
 int launch_median_begin_count(void* state, unsigned long long count, hipStream_t s);
-// lower median of a flat array (state: median_state_bytes()); mean / std / min / max / median of a flat array
-int launch_lower_median(const float* v, int64_t count, float* out, void* state, hipStream_t s);
+// lower median of a flat array (scratch: median_scratch_bytes(count)); mean / std / min / max / median of a flat array
+int launch_lower_median(const float* v, int64_t count, float* out, void* scratch, hipStream_t s);
 int launch_stats_finish(const void* part, int64_t nparts, const float* pivot, int64_t count, double* out, hipStream_t s);
 int launch_stats_set_median(const float* med, double* out, hipStream_t s);
 size_t stat_partial_bytes();
@@ -186,7 +200,7 @@ int64_t rbf_direct_blocks(int64_t n, int64_t m);
 int launch_rbf_direct_pivot(const void* X, const void* Y, int64_t d, int dtype, float lambda, float* pivot, hipStream_t s);
 int launch_rbf_direct(const void* X, int64_t n, const void* Y, int64_t m, int64_t d, int dtype, float lambda, float* out,
                       void* part, const float* pivot, hipStream_t s);
-size_t array_stats_scratch_bytes();
+size_t array_stats_scratch_bytes(int64_t count);
 int launch_array_stats(const float* v, int64_t count, double* out /*[5] device*/, void* scratch, hipStream_t s);
 int launch_threshold_edges_panel(const float* K, int64_t n, int64_t row0, int64_t rows, float thr, int64_t* ei_row,
                                  int64_t* ei_col, float* ew, int64_t capacity, int64_t* out_count, uint32_t* scratch,

@@ -2,7 +2,7 @@
 algorithmic bytes / flops per call divided by its measured time, against the roof that bounds it:
 HBM 8 TB/s, f32 MFMA 157.3 TFLOP/s, or — for the direct-difference RBF — the vector ALU (2 instructions per pair and k:
 3.93e13 pair-k/s at 2.4 GHz).  Prints one JSON object; profiles/rNN_rows.json is a copy.  Keys start with the §8 row id."""
-import json, sys, time, torch
+import json, os, sys, time, torch
 sys.path.insert(0, '.')
 import multimodal_fusion_amd as mmf
 ops = mmf.ops
@@ -48,7 +48,11 @@ out["a3 compute_combined_similarity: sim_dense_combined N=16384 d=512+2"] = mfma
 # a4: build_weighted_hypergraph = lower median of the off-diagonal + ordered threshold compaction on a materialised K
 K = ops.sim_dense_combined(F, P, 0.5, 0.001)
 t = timed(lambda: ops.offdiag_lower_median(K))
-out["a4 build_weighted_hypergraph: offdiag_lower_median N=16384"] = hbm(t, 4 * N * N * 4, note="4 radix passes over K")
+out["a4 build_weighted_hypergraph: offdiag_lower_median N=16384"] = hbm(t, N * N * 4, note="one sweep over K (sampled bracket + exact counts) + a select among the 3 % inside the bracket")
+os.environ["MMF_MEDIAN_RADIX"] = "1"
+t = timed(lambda: ops.offdiag_lower_median(K))
+del os.environ["MMF_MEDIAN_RADIX"]
+out["a4 build_weighted_hypergraph: offdiag_lower_median N=16384, four-pass radix select (MMF_MEDIAN_RADIX=1)"] = hbm(t, 4 * N * N * 4, note="4 radix passes over K")
 thr = float(ops.offdiag_lower_median(K))
 ei, ew = ops.threshold_edges(K, thr)
 E = ei.shape[1]
@@ -56,16 +60,24 @@ t = timed(lambda: ops.threshold_edges(K, thr), reps=5)
 out["a4 build_weighted_hypergraph: threshold_edges N=16384"] = hbm(t, 2 * N * N * 4 + E * 20, edges=E, note="count pass + fill pass over K, 20 B written per edge")
 # f4: the five statistics of a stored matrix (aggregate_wsi_super_patches' K_wsi): one reduction pass + 4 radix passes
 t = timed(lambda: ops.array_stats(K), reps=5)
-out["f4 similarity statistics of a stored matrix: array_stats N=16384"] = hbm(t, 5 * N * N * 4, note="1 reduction pass + 4 radix passes; torch: 4 reductions + a sort")
+out["f4 similarity statistics of a stored matrix: array_stats N=16384"] = hbm(t, 2 * N * N * 4, note="1 reduction pass + 1 median sweep; torch: 4 reductions + a sort")
+# f2: the same median with K never stored (recomputed in row panels)
+for env in ("", "1"):
+    if env:
+        os.environ["MMF_MEDIAN_RADIX"] = env
+    t = timed(lambda: ops.combined_offdiag_median(F, P, 0.5, 0.001), reps=3, warm=1)
+    os.environ.pop("MMF_MEDIAN_RADIX", None)
+    out["f2 combined_offdiag_median N=16384 d=512, K never stored" + (", four-pass radix select" if env else "")] = mfma(
+        t, (4 if env else 1) * 2 * N * N * d, note=("4" if env else "1") + " recomputation(s) of K")
 del K, ei, ew
 # a7: compute_wsi_tma_similarity — direct-difference RBF (VALU bound) with the statistics fused
 M = 16384
 A, B = rows(N, d, 5) * 0.7, rows(M, d, 6) * 0.7
 for name, fn in (("matrix only", lambda: ops.sim_dense(A, B, metric="rbf_direct", lam=1.0)),
                  ("matrix + mean/std/min/max/median", lambda: ops.sim_dense_stats(A, B, metric="rbf_direct", lam=1.0)),
-                 ("statistics only, matrix never stored (4 recomputations)", lambda: ops.sim_dense_stats(A, B, metric="rbf_direct", lam=1.0, store=False))):
+                 ("statistics only, matrix never stored (one recomputation: the median's single sweep)", lambda: ops.sim_dense_stats(A, B, metric="rbf_direct", lam=1.0, store=False))):
     t = timed(fn, reps=3, warm=1)
-    work = N * M * d * (4 if "never stored" in name else 1)
+    work = N * M * d
     out[f"a7 compute_wsi_tma_similarity: rbf_direct {N}x{M} d={d}, {name}"] = {
         "ms": t * 1e3, "bound": "valu (v_sub + v_fma per pair-k)", "pair-k/s": work / t, "frac": work / t / VALU_PAIRK,
         "write GB/s": 0.0 if "never" in name else N * M * 4 / t / 1e9}

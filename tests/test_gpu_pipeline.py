@@ -104,7 +104,7 @@ def test_knn_pairs_is_the_undirected_dedup_of_the_reference(mmf):
 
 
 # ------------------------------------------------------------------------------------------------ order statistics
-@pytest.mark.parametrize("count", [1, 2, 5, 4095, 4096, 4097, 65536 + 3, 3_000_001])
+@pytest.mark.parametrize("count", [1, 2, 5, 4095, 4096, 4097, 65536 + 3, 3_000_001, 4_700_003])
 def test_array_stats_and_lower_median_match_torch(mmf, count):
     ops = mmf.ops
     g = torch.Generator(device="cuda").manual_seed(count)
@@ -123,6 +123,58 @@ def test_array_stats_and_lower_median_match_torch(mmf, count):
         else:
             assert np.isnan(st["std"])
         assert repr(ops.array_stats(v)) == repr(st)          # bit-reproducible (repr: NaN compares unequal to itself)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "normal_tiny_range", "five_values", "constant", "bimodal", "sorted", "with_inf",
+                                  "negative", "unaligned"])
+def test_one_sweep_median_is_exact_and_falls_back(mmf, kind, monkeypatch):
+    """Populations of 4 M values or more take the sampled-bracket path (one sweep, exact counts); whatever the sample
+    says the result must be torch.median's element, and the four-pass radix select must agree (MMF_MEDIAN_RADIX=1)."""
+    ops = mmf.ops
+    count = 5_000_003
+    g = torch.Generator(device="cuda").manual_seed(11)
+    u = torch.rand(count + 1, generator=g, device="cuda")
+    if kind == "uniform":
+        v = u[:count]
+    elif kind == "normal_tiny_range":
+        v = (0.75 + 1e-6 * torch.randn(count, generator=g, device="cuda"))
+    elif kind == "five_values":
+        v = torch.floor(u[:count] * 5) * 0.125          # 20 % of the entries equal the median: the buffer overflows -> radix
+    elif kind == "constant":
+        v = torch.full((count,), 0.3125, device="cuda")
+    elif kind == "bimodal":
+        v = torch.where(u[:count] < 0.5, 0.1 * u[:count], 0.9 + 0.1 * u[:count])   # the median sits at the edge of a gap
+    elif kind == "sorted":
+        v = torch.sort(u[:count]).values
+    elif kind == "with_inf":
+        v = u[:count].clone(); v[::7] = float("inf"); v[3::11] = -float("inf")
+    elif kind == "negative":
+        v = -1e3 * u[:count] - 5.0
+    else:
+        v = u[1:count + 1]                               # 4-byte aligned only
+    ref = float(v.median())
+    assert float(ops.lower_median(v)) == ref, kind
+    assert ops.array_stats(v)["median"] == ref
+    monkeypatch.setenv("MMF_MEDIAN_RADIX", "1")
+    assert float(ops.lower_median(v)) == ref
+    monkeypatch.delenv("MMF_MEDIAN_RADIX")
+
+
+@pytest.mark.parametrize("n", [2300, 2051])
+def test_one_sweep_offdiag_median_on_structured_matrices(mmf, n):
+    """Off-diagonal medians of matrices with strong row / column effects (the sample is uniform over ENTRIES, so it does
+    not care) and a diagonal that would move the median if it were counted."""
+    ops = mmf.ops
+    g = torch.Generator(device="cuda").manual_seed(n)
+    r = torch.rand(n, 1, generator=g, device="cuda") ** 3
+    c = torch.rand(1, n, generator=g, device="cuda")
+    K = (r * c + 0.01 * torch.rand(n, n, generator=g, device="cuda")).contiguous()
+    K.fill_diagonal_(1e6)
+    off = K[~torch.eye(n, dtype=torch.bool, device="cuda")]
+    assert float(ops.offdiag_lower_median(K)) == float(off.median())
+    K2 = torch.exp(-3.0 * torch.rand(n, n, generator=g, device="cuda"))
+    K2 = torch.minimum(K2, K2.t()).contiguous()
+    assert float(ops.offdiag_lower_median(K2)) == float(K2[~torch.eye(n, dtype=torch.bool, device="cuda")].median())
 
 
 # ------------------------------------------------------------------------------------------------ a7 / f4
