@@ -248,8 +248,9 @@ int mmf_sim_dense(const void* X, int64_t n, const void* Y, int64_t m, int64_t d,
  * lower median, as device double[5] — replacing the `.mean()/.std()/.min()/.max()/.median()` passes of
  * compute_wsi_tma_similarity (build_hypergraph/preprocess_hypergraph.py:259-265).
  * MMF_RBF_DIRECT: the sums, minimum and maximum come out of the epilogue of the kernel that forms S (no extra pass);
- * the median is a 4-pass radix select over S.  out == NULL (MMF_RBF_DIRECT only): S is never stored — its rows are
- * recomputed in panels of `panel_rows` rows (0 = about 1 GiB) for every radix pass.
+ * the median is one more sweep over S (see "Lower medians" below).  out == NULL (MMF_RBF_DIRECT only): S is never
+ * stored — its rows are recomputed in panels of `panel_rows` rows (0 = about 1 GiB), once for the statistics and the
+ * median together (four more times if the median's one-sweep path has to fall back).
  * Other metrics: mmf_sim_dense followed by mmf_array_stats.   n, m >= 1.
  */
 int mmf_sim_dense_stats(const void* X, int64_t n, const void* Y, int64_t m, int64_t d,
@@ -273,6 +274,13 @@ int mmf_sim_dense_combined(const float* F, const float* P, int64_t n, int64_t d,
  *           build_hypergraph/similarity_kernel.py:183-202 (row-major order, self-loops kept).
  *   mmf_offdiag_lower_median: lower median (torch.median semantics) of the n(n-1) off-diagonal
  *                             entries; result written to *out_median (device f32).
+ * Lower medians (here, mmf_lower_median, mmf_array_stats, mmf_sim_dense_stats, mmf_combined_offdiag_median): a
+ * population of 2^22 values or more is first tried in ONE sweep — 32768 entries at hashed positions give a bracket
+ * [lo, hi] around the median, the sweep counts the entries below lo exactly and buffers the ~3 % inside the bracket,
+ * and the median is selected among those; the answer is exact (the sample only chooses where to look).  If the
+ * bracket misses the median's rank or the buffer overflows (many equal values), the four-pass radix select over the
+ * whole population runs instead; smaller populations always take it.  The one-sweep path synchronises the stream
+ * once (the bracket's verdict comes back to the host).  MMF_MEDIAN_RADIX=1 in the environment forces the radix path.
  *   mmf_threshold_edges:      keep (i,j) with K[i,j] >= threshold, row-major; writes at most
  *                             `capacity` edges, always writes the true count to *out_count
  *                             (device int64).  edge_index:[2,capacity] int64, edge_w:[capacity].
@@ -290,7 +298,7 @@ int mmf_threshold_edges(const float* K, int64_t n, float threshold,
  *   mmf_array_stats:  out_stats (device double[5]) = mean, std (unbiased, torch.std), min, max, lower median —
  *                     the similarity statistics of preprocess_hypergraph.py:186-197, 259-265, 849-855 — in one
  *                     reduction pass (f64 accumulation around a pivot, fixed merge order: bit-reproducible) plus
- *                     the 4-pass radix select, instead of five torch reductions and a full sort.
+ *                     the median's sweep, instead of five torch reductions and a full sort.
  * count < 1 -> MMF_E_INVALID.
  */
 int mmf_lower_median(const float* v, int64_t count, float* out_median, int device_id, void* hip_stream);
@@ -298,8 +306,9 @@ int mmf_array_stats(const float* v, int64_t count, double* out_stats, int device
 
 /*
  * The same two steps for an N whose combined similarity K = K_h * K_g ([n,n] f32) does not fit in
- * memory: K is recomputed from (F, P) in row panels of `panel_rows` rows (0 = about 1 GiB per panel) — four sweeps
- * for the median (one per radix byte), one sweep per call of the edge builder (capacity 0 counts, then fill).
+ * memory: K is recomputed from (F, P) in row panels of `panel_rows` rows (0 = about 1 GiB per panel) — one sweep
+ * for the median (four when its one-sweep path falls back), one sweep per call of the edge builder (capacity 0
+ * counts, then fill).
  * Results are those of mmf_sim_dense_combined + mmf_offdiag_lower_median / mmf_threshold_edges, bit for bit.
  */
 int mmf_combined_offdiag_median(const float* F, const float* P, int64_t n, int64_t d, int64_t dp,
