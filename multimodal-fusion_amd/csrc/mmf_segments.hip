@@ -36,17 +36,29 @@ __global__ __launch_bounds__(64) void seg_count_kernel(const int64_t* __restrict
   for (int s = threadIdx.x; s < S; s += 64) block_hist[(size_t)blockIdx.x * S + s] = hist[s];
 }
 
-// per label: exclusive prefix over the blocks (in place), total -> counts
-__global__ void seg_block_scan_kernel(uint32_t* __restrict__ block_hist, int nb, int S, int64_t* __restrict__ counts) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= S) return;
-  uint32_t run = 0;
-  for (int b = 0; b < nb; ++b) {
-    const uint32_t t = block_hist[(size_t)b * S + s];
-    block_hist[(size_t)b * S + s] = run;
-    run += t;
+// per label: exclusive prefix over the blocks (in place), total -> counts.  One workgroup per label; a thread owns a
+// run of consecutive blocks (a serial walk of 256 blocks per label was 61 us of dependent global round trips).
+__global__ __launch_bounds__(256) void seg_block_scan_kernel(uint32_t* __restrict__ block_hist, int nb, int S, int64_t* __restrict__ counts) {
+  __shared__ uint32_t part[256];
+  const int s = blockIdx.x, t = threadIdx.x;
+  const int per = (nb + 255) / 256, b0 = t * per, b1 = (b0 + per < nb) ? b0 + per : nb;
+  uint32_t sum = 0;
+  for (int b = b0; b < b1; ++b) sum += block_hist[(size_t)b * S + s];
+  part[t] = sum;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const uint32_t v = (t >= o) ? part[t - o] : 0u;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
   }
-  counts[s] = (int64_t)run;
+  uint32_t run = part[t] - sum;
+  for (int b = b0; b < b1; ++b) {
+    const uint32_t c = block_hist[(size_t)b * S + s];
+    block_hist[(size_t)b * S + s] = run;
+    run += c;
+  }
+  if (t == 255) counts[s] = (int64_t)part[255];
 }
 
 // offsets[0..S] = exclusive scan of counts (one workgroup; S <= SEG_MAX)
@@ -72,8 +84,10 @@ __global__ __launch_bounds__(1024) void seg_offsets_kernel(const int64_t* __rest
   if (t == 1023) offsets[S] = (int64_t)part[1023];
 }
 
-// stable scatter: one wave walks its chunk in row order; lanes that share a label rank themselves with ballots
-__global__ __launch_bounds__(64) void seg_scatter_kernel(const int64_t* __restrict__ labels, int64_t n, int S,
+// stable scatter: one wave walks its chunk in row order.  The lanes that share a label find each other with one ballot
+// per label BIT (the mask of lanes that agree with this lane on every bit), so a step costs the same however many
+// distinct labels its 64 rows carry (a leader loop over the distinct labels was 47 rounds per step at S = 100).
+__global__ __launch_bounds__(64) void seg_scatter_kernel(const int64_t* __restrict__ labels, int64_t n, int S, int bits,
                                                          const uint32_t* __restrict__ block_hist,
                                                          const int64_t* __restrict__ offsets, int64_t* __restrict__ order) {
   extern __shared__ uint32_t cursor[];     // position of the next member of each label, relative to offsets[label]
@@ -88,20 +102,20 @@ __global__ __launch_bounds__(64) void seg_scatter_kernel(const int64_t* __restri
       const int64_t ll = labels[r];
       if (ll >= 0 && ll < S) l = (int)ll;
     }
-    unsigned long long todo = __ballot(l >= 0);
-    while (todo) {
-      const int leader = __builtin_ctzll(todo);
-      const int lead_l = __shfl(l, leader);
-      const unsigned long long m = __ballot(l == lead_l);
-      if (l == lead_l) {
-        const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        order[offsets[l] + (int64_t)(cursor[l] + rank)] = r;
-      }
-      __syncthreads();                 // one wave per workgroup: orders the LDS read above before the update below
-      if (lane == leader) cursor[lead_l] += (uint32_t)__popcll(m);
-      __syncthreads();
-      todo &= ~m;
+    unsigned long long match = __ballot(l >= 0);
+    for (int b = 0; b < bits; ++b) {
+      const unsigned long long mb = __ballot((l >> b) & 1);
+      match &= ((l >> b) & 1) ? mb : ~mb;
     }
+    uint32_t cur = 0;
+    if (l >= 0) cur = cursor[l];
+    __syncthreads();                   // one wave per workgroup: orders the LDS reads above before the updates below
+    if (l >= 0) {
+      const uint32_t rank = (uint32_t)__popcll(match & ((1ull << lane) - 1ull));
+      order[offsets[l] + (int64_t)(cur + rank)] = r;
+      if (rank == 0) cursor[l] = cur + (uint32_t)__popcll(match);      // the label's first lane of this step
+    }
+    __syncthreads();
   }
 }
 
@@ -120,11 +134,13 @@ int launch_segment_sort(const int64_t* labels, int64_t n, int64_t S, int64_t* co
   MMF_HIP(hipMemsetAsync(bad, 0, 4, s));
   hipLaunchKernelGGL(seg_count_kernel, dim3((unsigned)nb), dim3(64), lds, s, labels, n, (int)S, block_hist, bad);
   MMF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(seg_block_scan_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, s, block_hist, nb, (int)S, counts);
+  hipLaunchKernelGGL(seg_block_scan_kernel, dim3((unsigned)S), dim3(256), 0, s, block_hist, nb, (int)S, counts);
   MMF_LAUNCH_CHECK();
   hipLaunchKernelGGL(seg_offsets_kernel, dim3(1), dim3(1024), 0, s, counts, (int)S, offsets);
   MMF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(seg_scatter_kernel, dim3((unsigned)nb), dim3(64), lds, s, labels, n, (int)S, block_hist, offsets, order);
+  int bits = 0;
+  while ((int64_t(1) << bits) < S) ++bits;
+  hipLaunchKernelGGL(seg_scatter_kernel, dim3((unsigned)nb), dim3(64), lds, s, labels, n, (int)S, bits, block_hist, offsets, order);
   MMF_LAUNCH_CHECK();
   return MMF_OK;
 }
@@ -145,10 +161,26 @@ __global__ __launch_bounds__(64 * SM_W) void seg_mean_kernel(const float* __rest
   float acc = 0.f;
   if (col < d) {
     int64_t q = b + w;
-    for (; q + 3 * SM_W < e; q += 4 * SM_W) {
-      const int64_t r0 = order[q], r1 = order[q + SM_W], r2 = order[q + 2 * SM_W], r3 = order[q + 3 * SM_W];
-      const float x0 = X[r0 * d + col], x1 = X[r1 * d + col], x2 = X[r2 * d + col], x3 = X[r3 * d + col];
-      acc += x0; acc += x1; acc += x2; acc += x3;
+    // eight row loads in flight per wave; the member indices of the NEXT trip are read while this trip's rows arrive
+    // (index -> row is two dependent round trips otherwise).  The adds stay in member order.
+    int64_t r[8];
+    bool more = q + 7 * SM_W < e;
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] = order[q + u * SM_W];
+    }
+    while (more) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = X[r[u] * d + col];
+      q += 8 * SM_W;
+      more = q + 7 * SM_W < e;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = order[q + u * SM_W];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += x[u];
     }
     for (; q < e; q += SM_W) acc += X[order[q] * d + col];
   }
@@ -286,12 +318,14 @@ int launch_clique_pairs(const int64_t* order, const int64_t* offsets, int64_t n,
 // ---- k-NN pairs -------------------------------------------------------------------------------------------------
 // Directed pair i -> j (j = nbr[i][t]) becomes the undirected (min, max).  It is dropped when a clique already holds it
 // (labels given and equal) or when the same pair is also emitted by the smaller row (j < i and i in nbr[j]): what is
-// left is duplicate-free without a sort.  Appended with one atomic per wave; the caller orders the union.
-__global__ __launch_bounds__(256) void knn_pairs_kernel(const int64_t* __restrict__ nbr, int64_t n, int k, const int64_t* __restrict__ labels,
-                                                        int64_t* __restrict__ lo, int64_t* __restrict__ hi,
-                                                        unsigned long long* __restrict__ count) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int lane = threadIdx.x & 63;
+// left is duplicate-free without a sort.  Appended with one atomic per workgroup; the caller orders the union.
+__global__ __launch_bounds__(1024) void knn_pairs_kernel(const int64_t* __restrict__ nbr, int64_t n, int k, const int64_t* __restrict__ labels,
+                                                         int64_t* __restrict__ lo, int64_t* __restrict__ hi,
+                                                         unsigned long long* __restrict__ count) {
+  __shared__ unsigned int wcnt[16];
+  __shared__ unsigned long long wbase;
+  const int64_t t = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   bool keep = false;
   int64_t i = 0, j = 0;
   if (t < n * k) {
@@ -304,14 +338,18 @@ __global__ __launch_bounds__(256) void knn_pairs_kernel(const int64_t* __restric
         if (nbr[j * k + u] == i) { keep = false; break; }
     }
   }
+  // one reservation per workgroup: 20 000 waves appending through one counter queued up at the L2 (0.25 ms for 1.3 M pairs)
   const unsigned long long m = __ballot(keep);
-  unsigned long long base = 0;
-  if (m) {
-    if (lane == __builtin_ctzll(m)) base = atomicAdd(count, (unsigned long long)__popcll(m));
-    base = __shfl(base, __builtin_ctzll(m));
+  if (lane == 0) wcnt[wave] = (unsigned int)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int run = 0;
+    for (int w = 0; w < 16; ++w) { const unsigned int c = wcnt[w]; wcnt[w] = run; run += c; }
+    wbase = run ? atomicAdd(count, (unsigned long long)run) : 0ull;
   }
+  __syncthreads();
   if (keep) {
-    const unsigned long long pos = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+    const unsigned long long pos = wbase + wcnt[wave] + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
     lo[pos] = i < j ? i : j;
     hi[pos] = i < j ? j : i;
   }
@@ -322,7 +360,7 @@ int launch_knn_pairs(const int64_t* nbr, int64_t n, int k, const int64_t* labels
   MMF_HIP(hipMemsetAsync(out_count, 0, 8, s));
   const int64_t total = n * k;
   if (total == 0) return MMF_OK;
-  hipLaunchKernelGGL(knn_pairs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, nbr, n, k, labels, lo, hi,
+  hipLaunchKernelGGL(knn_pairs_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, nbr, n, k, labels, lo, hi,
                      reinterpret_cast<unsigned long long*>(out_count));
   MMF_LAUNCH_CHECK();
   return MMF_OK;
