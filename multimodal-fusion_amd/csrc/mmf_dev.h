@@ -394,19 +394,43 @@ struct LaneList {
 // slots per query, shared by every lane, workgroup and launch that scans the query).  Near-duplicate data puts far
 // more columns inside a query's margin band than a list has entries; they are kept here, not dropped, and the
 // exact re-rank reads them with the lists.  cap == 0: no sink (a full list then loses the key, audited).
+#ifndef MMF_SINK_CHUNK
+#define MMF_SINK_CHUNK 8u      // A/B switches of scripts/ab_build.sh: -DMMF_SINK_CHUNK=1u, -DMMF_BAND_DIRECT=0
+#endif
+#ifndef MMF_BAND_DIRECT
+#define MMF_BAND_DIRECT 1
+#endif
 struct SpillSink {
   uint32_t* cnt = nullptr;    // [rows]
   uint32_t* ids = nullptr;    // [rows][cap]
   uint32_t cap = 0;
   uint32_t seg_len = 0, seg_stride = 0, id_off = 0;   // operand column -> reported id (ScanB16Args)
   int64_t row = 0;
-  __device__ __forceinline__ bool put(uint32_t id) const {
+  int ablate = 0;   // timing-only (MMF_SCAN_DEBUG bit 128): pretend the entry was stored
+  // A lane reserves slots with a returning atomic on the row's counter — a round trip to the L2 the wave waits for.  A
+  // lane that is known to have many entries coming (bulk: its list is crowded) reserves kChunk slots at a time and fills
+  // them privately; what it has not used when the scan ends is closed with kEmpty, which the reader skips.  The
+  // counter therefore counts RESERVED slots and may pass `cap` (the reader clamps; a reservation that starts at or
+  // beyond cap fails, and the caller records the key as lost).
+  static constexpr uint32_t kChunk = MMF_SINK_CHUNK, kEmpty = 0xffffffffu;
+  uint32_t cpos = 0, cleft = 0;
+  __device__ __forceinline__ bool put(uint32_t id, bool bulk) {
     if (cap == 0) return false;
-    const uint32_t pos = atomicAdd(cnt + row, 1u);
-    if (pos >= cap) return false;
+    if (ablate) return true;
+    if (cleft == 0) {
+      const uint32_t want = bulk ? kChunk : 1u;
+      const uint32_t base = atomicAdd(cnt + row, want);
+      if (base >= cap) return false;
+      cpos = base;
+      cleft = (cap - base < want) ? (cap - base) : want;
+    }
     if (seg_len) id = (id / seg_len) * seg_stride + id % seg_len;
-    ids[row * cap + pos] = id + id_off;
+    ids[row * cap + cpos] = id + id_off;
+    ++cpos; --cleft;
     return true;
+  }
+  __device__ __forceinline__ void close() {
+    while (cleft != 0) { ids[row * cap + cpos] = kEmpty; ++cpos; --cleft; }
   }
 };
 
@@ -424,12 +448,16 @@ struct SlotList {
   float thr;
   float lost;
   uint32_t overflow;
+  float tband;        // crowded lists only: the k-th best key the partner lists have proved (top of the margin band), else +inf..-inf
+                      //   = -inf until a compaction finds the band fuller than the list: from then on a hit BELOW it cannot move
+                      //   the threshold any more and goes straight to the overflow list (no push, no compaction)
 
   __device__ __forceinline__ void init(float* k, uint32_t* ids) {
-    keys = k; idslot = ids; cnt = 0; used = 0; thr = -kFltMax; lost = kNegInf; overflow = 0;
+    keys = k; idslot = ids; cnt = 0; used = 0; thr = -kFltMax; lost = kNegInf; overflow = 0; tband = kNegInf;
   }
   __device__ __forceinline__ void finish() {
     if (lost >= thr) overflow = 1;
+    sink.close();
   }
   __device__ __forceinline__ void push(float key, uint32_t id) {   // requires cnt < CAP
     const int sl = __builtin_ctz(~used);
@@ -508,6 +536,7 @@ struct SlotList {
       const bool deep = sink.cap != 0 && kk + 2 <= SMALL;
       cut = deep ? k[SMALL - 1] : k[CAP - 3];
       room = deep ? SMALL : CAP - 2;
+      if (sink.cap != 0 && t > tband) tband = t;
     }
     int w = 0;
     uint32_t nused = 0;
@@ -516,7 +545,7 @@ struct SlotList {
       if (ke >= cut && w < room) {
         keys[w * NT] = ke; nused |= 1u << (__float_as_uint(ke) & SLOTMASK); ++w;
       } else if (ke >= thr) {           // still inside the band: to the overflow list, else lost (audited)
-        if (!sink.put(idslot[(__float_as_uint(ke) & SLOTMASK) * NT])) lost = fmaxf(lost, ke);
+        if (!sink.put(idslot[(__float_as_uint(ke) & SLOTMASK) * NT], tband != kNegInf)) lost = fmaxf(lost, ke);
       }
     }
     thr = fmaxf(thr, lost);
@@ -574,6 +603,7 @@ struct SlotList {
       for (int i = 0; i < BLK; ++i) keep += ((e0 + i < cnt) && keys[(e0 + i) * NT] >= thr) ? 1 : 0;
     }
     const bool crowded = keep >= CAP - 1;               // only the lane's best room_crowded entries stay then
+    if (crowded && sink.cap != 0 && t > tband) tband = t;
     int w = 0;
     uint32_t nused = 0;
     for (int e0 = 0; e0 < cnt; e0 += BLK) {             // in-place filter: a block is in registers before it is overwritten
@@ -588,7 +618,7 @@ struct SlotList {
         if (stay && w < CAP - 2) {
           keys[w * NT] = ke; nused |= 1u << (__float_as_uint(ke) & SLOTMASK); ++w;
         } else if (live) {
-          if (!sink.put(idslot[(__float_as_uint(ke) & SLOTMASK) * NT])) lost = fmaxf(lost, ke);
+          if (!sink.put(idslot[(__float_as_uint(ke) & SLOTMASK) * NT], tband != kNegInf)) lost = fmaxf(lost, ke);
         }
       }
     }
@@ -613,14 +643,15 @@ struct SlotList {
       rmask &= rmask - 1;
       const float x = v[r];
       bool hit = x >= thr;
-      if (__any(hit && cnt >= CAP)) {
+      const bool band = MMF_BAND_DIRECT && x < tband;
+      if (__any(hit && !band && cnt >= CAP)) {
         compact(kk, margin);
         hit = x >= thr;
       }
       if (hit) {
-        if (cnt < CAP) {
+        if (__builtin_expect(!band && cnt < CAP, 1)) {
           push(x, id0 + rowof(r));
-        } else if (!sink.put(id0 + rowof(r))) {
+        } else if (!sink.put(id0 + rowof(r), tband != kNegInf)) {     // a band entry of a crowded list, or a hit that found the list full
           lost = fmaxf(lost, x);
           thr = fmaxf(thr, lost);
         }

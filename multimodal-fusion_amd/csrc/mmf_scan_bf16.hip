@@ -329,6 +329,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
   else if (a.spill_cnt) {
     list.sink.cnt = a.spill_cnt; list.sink.ids = a.spill_ids; list.sink.cap = (uint32_t)a.spill_cap; list.sink.row = qpos;
     list.sink.seg_len = a.seg_len; list.sink.seg_stride = a.seg_stride; list.sink.id_off = a.id_off;
+    if (DBG) list.sink.ablate = (a.debug & 128) ? 1 : 0;
   }
   // Thresholds are shared between the workgroups (and launches) that scan different columns for the same
   // queries: any list's threshold bounds the approximate key of every member of the final top-k, whatever
@@ -649,6 +650,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
   __builtin_amdgcn_s_waitcnt(0x0F70);   // the dummy tiles still in flight
 
   list.compact(a.kk, margin);
+  list.sink.close();                    // reserved overflow-list slots this lane did not use
   sync_seed();
   if (qvalid) {
     const int64_t lbase = qpos * a.lists_total + a.list_base + 2 * split + half;

@@ -91,16 +91,25 @@ __device__ __forceinline__ int gather_candidates(const SelectArgs& a, int64_t po
   }
   // the row's overflow list (columns the lane lists had no room for): appended after the pruning below, which
   // works on approximate keys these entries do not carry
+  // The counter counts RESERVED slots (lanes reserve in chunks, SpillSink): it may pass the capacity — a reservation
+  // that found no room recorded its key as lost, and the audit flags the row if that key mattered — and reserved slots a
+  // lane did not use hold 0xffffffff.
   int n_sp = 0;
   if (a.spill_cnt) {
     const uint32_t c = a.spill_cnt[pos];
-    if (c > (uint32_t)a.spill_cap) return -1;            // the sink overflowed too: the scan recorded a lost key
-    n_sp = (int)c;
+    n_sp = (int)(c < (uint32_t)a.spill_cap ? c : (uint32_t)a.spill_cap);
   }
   auto append_spill = [&](int at) -> int {
     if (at + n_sp > maxc) return -1;
-    for (int e = lane; e < n_sp; e += 64) id[at + e] = a.spill_ids[pos * a.spill_cap + e];
-    return at + n_sp;
+    for (int e0 = 0; e0 < n_sp; e0 += 64) {
+      const int e = e0 + lane;
+      const uint32_t v = (e < n_sp) ? a.spill_ids[pos * a.spill_cap + e] : 0xffffffffu;
+      const bool keep = v != 0xffffffffu;
+      const unsigned long long mask = __ballot(keep);
+      if (keep) id[at + __popcll(mask & ((1ull << lane) - 1ull))] = v;
+      at += __popcll(mask);
+    }
+    return at;
   };
   const int kk = a.k + (a.exclude_self ? 1 : 0);
   if (!prune || total <= kk) return append_spill(total);
