@@ -5,7 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import multimodal_fusion_amd as mmf
 from bench import make_rows
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
-X = make_rows(0, N, 512, torch.device("cuda", 0))
+D = int(sys.argv[2]) if len(sys.argv) > 2 else 512          # scripts/ablate.py 131072 1024 half: the split-k variant
+X = make_rows(0, N, D, torch.device("cuda", 0))
+if len(sys.argv) > 3 and sys.argv[3] == "half":
+    X = X.half()
 modes = [("production", None), ("dbg build", 64), ("no list code", 65), ("no DMA", 66), ("no barrier", 68), ("no list, no DMA", 67),
          ("no list, no barrier", 69), ("no list, DMA, barrier", 71), ("no list, DMA of tile 0 only", 64 + 1 + 32)]
 res = {m: [] for m, _ in modes}
@@ -24,4 +27,5 @@ for r in range(4):
 os.environ.pop("MMF_SCAN_DEBUG", None)
 for name, _ in modes:
     if res[name]:
-        print(f"{name:24s} {statistics.median(res[name]):8.3f} ms")
+        t = statistics.median(res[name])
+        print(f"{name:28s} {t:8.3f} ms  {2.0 * N * N * D / t / 1e9 / 2500.0:.3f} of peak")
