@@ -161,7 +161,8 @@ def topk_merge(ia: torch.Tensor, va: torch.Tensor, ib: torch.Tensor, vb: torch.T
 
 
 def offdiag_lower_median(K: torch.Tensor) -> torch.Tensor:
-    """Lower median of the off-diagonal entries of a square f32 matrix; returns a 0-d device tensor."""
+    """Lower median of the off-diagonal entries of a square f32 matrix; returns a 0-d device tensor (one sweep over K for
+    n >= 2049, include/mmf_hg.h "Lower medians")."""
     _need_gpu(K, "offdiag_lower_median")
     K = K.contiguous().float()
     if K.dim() != 2 or K.shape[0] != K.shape[1]:
@@ -173,7 +174,8 @@ def offdiag_lower_median(K: torch.Tensor) -> torch.Tensor:
 
 
 def lower_median(v: torch.Tensor) -> torch.Tensor:
-    """torch.median of a flat f32 tensor (lower median) by a 4-pass radix select; returns a 0-d device tensor."""
+    """torch.median of a flat f32 tensor (lower median); returns a 0-d device tensor.  4 M values or more: one sweep
+    (sampled bracket verified by exact counts, include/mmf_hg.h "Lower medians"), else a 4-pass radix select."""
     _need_gpu(v, "lower_median")
     v = v.contiguous().float().reshape(-1)
     if v.numel() < 1:
