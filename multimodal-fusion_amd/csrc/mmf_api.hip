@@ -182,7 +182,6 @@ struct FastTail {
   static constexpr int kSpillCap = 192;
   int64_t rows_exact_cap = 0;
   float* row_keys = nullptr;
-  int32_t* defer_rows = nullptr; uint32_t* defer_count = nullptr;
   // m_panel_min: columns of the smallest panel (== m_ when the scan is one launch); `splits` is per launch
   FastTail(int64_t n_, int64_t m_, int kk_, int cap_, int forced_splits, int dp_, int panels_ = 1, int64_t m_panel_min = -1)
       : n(n_), m(m_), kk(kk_), cap(cap_), dp(dp_), panels(panels_) {
@@ -226,7 +225,7 @@ struct FastTail {
     return ws_bytes((size_t)n * lists, 4) + 2 * ws_bytes((size_t)n * lists * bcap, 4) + 3 * ws_bytes(n, 4) + ws_bytes(4, 4) +
            ws_bytes(256, 4) + ws_bytes((size_t)FB * fb_lists, 4) + ws_bytes((size_t)FB * fb_lists * cap, 4) +
            2 * ws_bytes(FB, 4) + ws_bytes(4, 4) + ws_bytes(scan_b16_scratch_bytes(n, max_splits, dp, bcap), 1) + ws_bytes(2 * n_seed, 4) +
-           ws_bytes((size_t)rows_exact_cap * m, 4) + ws_bytes(n, 4) + ws_bytes((size_t)n * kSpillCap, 4) + ws_bytes(n, 4) + ws_bytes(4, 4);
+           ws_bytes((size_t)rows_exact_cap * m, 4) + ws_bytes(n, 4) + ws_bytes((size_t)n * kSpillCap, 4);
   }
   void carve(Workspace& ws) {
     L.cnt = ws.take<uint32_t>((size_t)n * lists);
@@ -251,8 +250,6 @@ struct FastTail {
     L.spill_cnt = ws.take<uint32_t>(n);
     L.spill_ids = ws.take<uint32_t>((size_t)n * kSpillCap);
     L.spill_cap = kSpillCap;
-    defer_rows = ws.take<int32_t>(n);
-    defer_count = ws.take<uint32_t>(4);
   }
   int run(const void* X, int64_t n_, const void* Y, int64_t m_, int64_t d, int in_dtype, int metric, float lambda, int k,
           int exclude_self, int64_t row_offset, int64_t col_offset, const FastOperands& fo, int64_t* out_idx,
@@ -265,7 +262,6 @@ struct FastTail {
     int grid = 0;
     MMF_HIP(hipMemsetAsync(seed, 0x80, (size_t)n_seed * 8, s));   // kSeedNone, thresholds and dropped keys
     MMF_HIP(hipMemsetAsync(L.spill_cnt, 0, (size_t)n * 4, s));
-    MMF_HIP(hipMemsetAsync(defer_count, 0, 16, s));
     MMF_TRY(t_scan.start(profile, s));
     ScanB16Panel pn;
     pn.seed = seed; pn.seed_stride = n_seed;
@@ -304,7 +300,7 @@ struct FastTail {
     q.k = k; q.exclude_self = exclude_self; q.row_offset = row_offset; q.col_offset = col_offset;
     q.rx = fo.rx; q.cy = fo.cy; q.row_ids = nullptr; q.n_rows = n; q.out_idx = out_idx; q.out_val = out_val;
     q.fail_rows = fail_rows; q.fail_count = fail_count; q.cand_total = stats ? cand_total : nullptr;
-    q.defer_rows = defer_rows; q.defer_count = defer_count;
+    q.two_pass = true;
     MMF_TRY(t_sel.start(profile, s));
     MMF_TRY(launch_select(q, L, s));
     MMF_TRY(t_sel.stop(s));

@@ -72,85 +72,28 @@ __device__ __forceinline__ bool better(float ka, uint32_t ia, float kb, uint32_t
 }
 
 // ---------------------------------------------------------------------------------------------
-// register sorting network (bitonic, fully unrolled): descending by (key, id)
-// ---------------------------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ void sort_desc(float (&k)[N], uint32_t (&id)[N]) {
-#pragma unroll
-  for (int size = 2; size <= N; size <<= 1) {
-#pragma unroll
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        const int j = i ^ stride;
-        if (j > i) {
-          const bool desc = ((i & size) == 0);
-          const bool sw = desc ? better(k[j], id[j], k[i], id[i]) : better(k[i], id[i], k[j], id[j]);
-          const float tk = sw ? k[j] : k[i];
-          const float uk = sw ? k[i] : k[j];
-          const uint32_t ti = sw ? id[j] : id[i];
-          const uint32_t ui = sw ? id[i] : id[j];
-          k[i] = tk; k[j] = uk; id[i] = ti; id[j] = ui;
-        }
-      }
-    }
-  }
-}
-
-// merge step of the same network: input bitonic, output descending
-template <int N>
-__device__ __forceinline__ void bitonic_merge_desc(float (&k)[N], uint32_t (&id)[N]) {
-#pragma unroll
-  for (int stride = N >> 1; stride > 0; stride >>= 1) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const int j = i ^ stride;
-      if (j > i) {
-        const bool sw = better(k[j], id[j], k[i], id[i]);
-        const float tk = sw ? k[j] : k[i];
-        const float uk = sw ? k[i] : k[j];
-        const uint32_t ti = sw ? id[j] : id[i];
-        const uint32_t ui = sw ? id[i] : id[j];
-        k[i] = tk; k[j] = uk; id[i] = ti; id[j] = ui;
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Lane-private candidate list.
+// LaneList — the lane-private candidate list of the EXACT scan (mmf_scan_f32.hip): final keys.
 //
-// In both scan kernels a lane owns ONE query (MFMA column = lane & 31) and sees half of every
-// 32-candidate tile (lane >> 5 picks the half), so candidates of a query are collected by exactly
-// two lanes, l and l ^ 32, each into its own list: no atomics, no cross-wave traffic.
-// Entry e of thread t lives at keys[e * NT + t] / ids[e * NT + t] (NT = threads per block):
-// consecutive lanes hit consecutive banks.
+// A lane owns ONE query (MFMA column = lane & 31) and sees half of every 32-candidate sub-tile
+// (lane >> 5 picks the half), so candidates of a query are collected by exactly two lanes, l and
+// l ^ 32, each into its own list: no atomics, no cross-wave traffic.  Entry e of thread t lives at
+// keys[e * NT + t] / ids[e * NT + t] (NT = threads per block): consecutive lanes hit consecutive banks.
 //
-// Invariant: thr <= (kk-th best key of the query over everything scanned so far) - margin, so a
-// column whose key can still belong to the final top-kk always passes `key >= thr`.
+// Invariant: thr <= kk-th best key of the query over everything scanned so far, so a column that can
+// still belong to the final top-kk always passes `key >= thr`.  Keys are final, so a compaction
+// truncates the pair of lists to the top kk by the total order (key desc, id asc) and nothing is ever
+// lost: the list cannot overflow (`overflow` is a guard that stays 0).
 // ---------------------------------------------------------------------------------------------
 template <int CAP, int NT>
 struct LaneList {
-  static constexpr int SORTN = (CAP <= 16) ? 16 : 32;
   float* keys;     // LDS, already offset by threadIdx.x
   uint32_t* ids;   // LDS, already offset by threadIdx.x
   int cnt;
   float thr;
-  float lost;      // best approximate key ever dropped by a lossy truncation (-inf: nothing lost)
   uint32_t overflow;
 
   __device__ __forceinline__ void init(float* k, uint32_t* i) {
-    keys = k; ids = i; cnt = 0; thr = -kFltMax; lost = kNegInf; overflow = 0;
-  }
-
-  // Approximate mode only.  A list can be crowded TRANSIENTLY: early in a scan the threshold is low
-  // and a cluster of near-identical columns puts more than CAP entries inside the margin band of
-  // the current k-th best, although the final top-k ends far above them.  So crowding truncates
-  // (lossy) instead of failing: the best dropped key is remembered in `lost`, the threshold is
-  // raised to it (nothing at or below a lost level is worth collecting), and the row fails only
-  // if, at the END, the final band still reaches down to a lost level: finish() checks that.
-  __device__ __forceinline__ void finish() {
-    if (lost >= thr) overflow = 1;
+    keys = k; ids = i; cnt = 0; thr = -kFltMax; overflow = 0;
   }
 
   __device__ __forceinline__ void push(float key, uint32_t id) {
@@ -159,149 +102,21 @@ struct LaneList {
     ++cnt;
   }
 
-  // Wave-wide (every lane of the wave calls it, EXEC full).  kk = entries a query must retain,
-  // margin = 0 with EXACT = true (keys are final: truncate to the top kk by the total order),
-  // margin = 2e > 0 otherwise (keys are approximate: keep everything within the margin).
-  template <bool EXACT>
-  __device__ __forceinline__ void compact(int kk, float margin) {
-    // Final keys always rank by counting: the (key, id) sorting network of compact_pairs holds so many compare masks
-    // that the exact scan's hot loop paid for it in spilled scalar registers (1400 spills, v_readlane in every chunk).
-    if constexpr (CAP <= 16 && !EXACT) compact_sorted<EXACT>(kk, margin);
-    else compact_ranked<EXACT>(kk, margin);
-  }
-
-  __device__ __forceinline__ void raise_thr(float t, float margin, bool exact) {
-    // fewer than kk real entries in the union -> t = -inf -> keep collecting everything
-    const float nthr = (t == kNegInf) ? -kFltMax : (exact ? t : (t - margin));
-    if (nthr > thr) thr = nthr;
-  }
-
-  // CAP <= 16.
-  template <bool EXACT>
-  __device__ __forceinline__ void compact_sorted(int kk, float margin) {
-    if constexpr (EXACT) compact_pairs(kk);
-    else compact_keys(kk, margin);
-  }
-
-  // Final keys (exact scan): the merge must break key ties by id, so (key, id) pairs are sorted in
-  // registers by a bitonic network and merged with the partner lane's.
-  __device__ __forceinline__ void compact_pairs(int kk) {
-    float k[SORTN];
-    uint32_t id[SORTN];
-#pragma unroll
-    for (int e = 0; e < SORTN; ++e) {
-      const bool live = (e < CAP) && (e < cnt);
-      k[e] = live ? keys[(e < CAP ? e : 0) * NT] : kNegInf;
-      id[e] = live ? ids[(e < CAP ? e : 0) * NT] : kNoIdx;
-    }
-    sort_desc<SORTN>(k, id);
-    // top SORTN of the union with the partner lane (same query, other half of every tile):
-    // c[i] = best(a[i], b[SORTN-1-i]) is the bitonic partition of two descending lists.
-    float c[SORTN];
-    uint32_t ci[SORTN];
-#pragma unroll
-    for (int e = 0; e < SORTN; ++e) {
-      const float pk = __shfl_xor(k[SORTN - 1 - e], 32);
-      const uint32_t pi = (uint32_t)__shfl_xor((int)id[SORTN - 1 - e], 32);
-      const bool own = better(k[e], id[e], pk, pi);
-      c[e] = own ? k[e] : pk;
-      ci[e] = own ? id[e] : pi;
-    }
-    bitonic_merge_desc<SORTN>(c, ci);
-    float t = kNegInf;
-#pragma unroll
-    for (int e = 0; e < SORTN; ++e) {
-      if (e == kk - 1) t = c[e];
-    }
-    raise_thr(t, 0.0f, true);
-    int keep = 0;
-#pragma unroll
-    for (int e = 0; e < CAP; ++e) keep += ((e < cnt) && (k[e] >= thr)) ? 1 : 0;
-    if (keep > kk) keep = kk;  // own top-kk by the total order is all the union can need
-#pragma unroll
-    for (int e = 0; e < CAP; ++e) {
-      if (e < keep) { keys[e * NT] = k[e]; ids[e * NT] = id[e]; }
-    }
-    cnt = keep;
-  }
-
-  // Approximate keys (16-bit scan): only the KEY order matters.  Sort the bare keys (a pure
-  // v_max/v_min network, 16 registers), take the kk-th best of the union with the partner lane,
-  // then filter the list in place in LDS.  Always leaves at least two free slots; what it has to
-  // drop for that is recorded in `lost` (see finish()).
-  __device__ __forceinline__ void compact_keys(int kk, float margin) {
-    float k[SORTN];
-#pragma unroll
-    for (int e = 0; e < SORTN; ++e) k[e] = ((e < CAP) && (e < cnt)) ? keys[(e < CAP ? e : 0) * NT] : kNegInf;
-#pragma unroll
-    for (int size = 2; size <= SORTN; size <<= 1) {
-#pragma unroll
-      for (int stride = size >> 1; stride > 0; stride >>= 1) {
-#pragma unroll
-        for (int i = 0; i < SORTN; ++i) {
-          const int j = i ^ stride;
-          if (j > i) {
-            const float hi = fmaxf(k[i], k[j]), lo = fminf(k[i], k[j]);
-            if ((i & size) == 0) { k[i] = hi; k[j] = lo; } else { k[i] = lo; k[j] = hi; }
-          }
-        }
-      }
-    }
-    // c[i] = max(a[i], b[SORTN-1-i]): bitonic partition of two descending lists = top SORTN of the union
-    float c[SORTN];
-#pragma unroll
-    for (int e = 0; e < SORTN; ++e) c[e] = fmaxf(k[e], __shfl_xor(k[SORTN - 1 - e], 32));
-#pragma unroll
-    for (int stride = SORTN >> 1; stride > 0; stride >>= 1) {
-#pragma unroll
-      for (int i = 0; i < SORTN; ++i) {
-        const int j = i ^ stride;
-        if (j > i) {
-          const float hi = fmaxf(c[i], c[j]), lo = fminf(c[i], c[j]);
-          c[i] = hi; c[j] = lo;
-        }
-      }
-    }
-    float t = kNegInf;
-#pragma unroll
-    for (int e = 0; e < SORTN; ++e) {
-      if (e == kk - 1) t = c[e];
-    }
-    raise_thr(t, margin, false);
-    int keep = 0;
-#pragma unroll
-    for (int e = 0; e < CAP; ++e) keep += ((e < cnt) && (k[e] >= thr)) ? 1 : 0;
-    float cut = thr;
-    if (keep >= CAP - 1) {       // crowded: (nearly) every slot is inside the band -> lossy truncation
-      lost = fmaxf(lost, k[CAP - 2]);   // sorted descending: the best entry being dropped
-      thr = fmaxf(thr, lost);
-      cut = k[CAP - 3];                 // keep the CAP-2 best: two free slots
-    }
-    int w = 0;
-    for (int e = 0; e < cnt; ++e) {     // in-place filter, lane-private
-      const float ke = keys[e * NT];
-      const uint32_t ie = ids[e * NT];
-      if (ke >= cut) {
-        if (w < CAP - 2) { keys[w * NT] = ke; ids[w * NT] = ie; ++w; }
-        else lost = fmaxf(lost, ke);    // ties at the cut beyond the guaranteed free slots
-      }
-    }
-    thr = fmaxf(thr, lost);
-    cnt = w;
-  }
-
-  // CAP > 16 (large k; CAP <= 64): ranks by counting straight out of LDS; the partner's list is read in place (same
-  // wave, so its LDS writes are already ordered before these reads).  Eight entries are ranked per sweep over the
-  // two lists: one pair of ds_reads feeds eight compares, and the reads of a sweep pipeline (one entry per sweep
-  // waited for every read).  The total order (key desc, id asc) is one signed 64-bit compare of
-  // (order-preserving key bits : ~id); -0.0 is folded into +0.0 first, as the float compare of better() does.
+  // The total order (key desc, id asc) as ONE signed 64-bit compare of (order-preserving key bits : ~id);
+  // -0.0 is folded into +0.0 first, as the float compare of better() does.
   static __device__ __forceinline__ long long order64(float key, uint32_t id) {
     const int b = __float_as_int(key + 0.0f);
     const int e = b >= 0 ? b : (b ^ 0x7fffffff);
     return (long long)(((unsigned long long)(uint32_t)e << 32) | (unsigned long long)(~id));
   }
-  template <bool EXACT>
-  __device__ __forceinline__ void compact_ranked(int kk, float margin) {
+
+  // Wave-wide (every lane of the wave calls it, EXEC full).  kk = entries a query must retain.  Every entry is
+  // ranked by COUNTING the entries of its own and its partner lane's list that beat it, straight out of LDS (same
+  // wave, so the partner's writes are ordered before these reads), eight entries per sweep: one pair of ds_reads
+  // feeds eight compares and the reads of a sweep pipeline (one entry per sweep waited for every read; a (key, id)
+  // sorting network in registers, the first version for 16 entries, cost the hot loop 1 400 spilled scalar registers).
+  // The entry of union rank kk - 1 is the new threshold; a lane keeps what passes it among its own top kk.
+  __device__ __forceinline__ void compact(int kk) {
     constexpr int BLK = 8;
     const int pofs = (int)((threadIdx.x ^ 32u) - threadIdx.x);
     const int pcnt = __shfl_xor(cnt, 32);
@@ -332,32 +147,23 @@ struct LaneList {
       }
     }
     const float t = fmaxf(t_own, __shfl_xor(t_own, 32));
-    raise_thr(t, margin, EXACT);
+    if (t != kNegInf && t > thr) thr = t;               // fewer than kk entries in the union: keep collecting everything
     int w = 0;
     for (int e = 0; e < cnt; ++e) {
       const float ke = keys[e * NT];
       const uint32_t ie = ids[e * NT];
-      const bool kp = (ke >= thr) && (!EXACT || ((topmask >> e) & 1ull));
-      if (kp) {
+      if ((ke >= thr) && ((topmask >> e) & 1ull)) {
         keys[w * NT] = ke;
         ids[w * NT] = ie;
         ++w;
       }
-    }
-    if (!EXACT && w >= CAP - 1) {  // crowded (see finish()): keep the first CAP-4, remember the best dropped
-      float best_dropped = kNegInf;
-      for (int e = CAP - 4; e < w; ++e) best_dropped = fmaxf(best_dropped, keys[e * NT]);
-      lost = fmaxf(lost, best_dropped);
-      thr = fmaxf(thr, lost);
-      w = CAP - 4;
     }
     cnt = w;
   }
 
   // Offer the 16 keys one lane holds for one 32x32 accumulator tile.  v[r] belongs to candidate
   // id0 + (r&3) + 8*(r>>2) + 4*(lane>>5).  Called by the whole wave when any lane has a hit.
-  template <bool EXACT>
-  __device__ __forceinline__ void offer_tile(const f32x16& v, uint32_t id0, int half, int kk, float margin) {
+  __device__ __forceinline__ void offer_tile(const f32x16& v, uint32_t id0, int half, int kk) {
     // only the accumulator rows that hold a hit in some lane run the push code (16 branch-free compares find them;
     // thr only rises meanwhile, so the mask is a superset)
     uint32_t rmask = 0;
@@ -369,7 +175,7 @@ struct LaneList {
       const float x = v[r];
       bool hit = x >= thr;
       if (__any(hit && cnt >= CAP)) {
-        compact<EXACT>(kk, margin);
+        compact(kk);
         hit = x >= thr;
       }
       if (hit) {
@@ -388,7 +194,14 @@ struct LaneList {
 // (idslot[s * NT + t]) that is written once on push and read once when the scan ends.  Compaction
 // therefore sorts / filters bare keys in LDS and never touches global memory.  The <= 15 ulp the
 // slot bits perturb a key by are part of the error margin (scan kernel, E1).
-// Thresholds, partner-lane merge and the audited-loss rule are those of LaneList.
+// A lane owns one query and half of every tile like LaneList (partner lane l ^ 32); keys are APPROXIMATE here, so
+//   * the threshold is  thr = (kk-th best key of the pair's union) - margin  (margin = 2 x the proven error bound of
+//     an approximate key, scan kernel): every column whose EXACT key can be in the final top-kk passes `key >= thr`;
+//   * a list can be crowded — more entries inside the band [t - margin, t] than it holds (near-duplicate data).  What
+//     it cannot hold goes to the row's overflow list (SpillSink); without one, or with it full, the best dropped key
+//     is remembered in `lost`, the threshold rises to it, and after the last launch the audit flags the row for an
+//     exact rescan if that key reaches the best threshold any list of the row proved (audited loss: a transient
+//     crowd early in a scan, far below the final band, costs nothing).
 // ---------------------------------------------------------------------------------------------
 // Where a full list puts what it cannot hold: the row's overflow list in global memory (one counter + `cap` id
 // slots per query, shared by every lane, workgroup and launch that scans the query).  Near-duplicate data puts far

@@ -146,7 +146,7 @@ struct SelectProblem {
   int64_t* out_idx; float* out_val;
   int32_t* fail_rows; uint32_t* fail_count;   // rows whose lists overflowed (or came up short)
   uint32_t* cand_total;                        // optional accumulated candidate count
-  int32_t* defer_rows = nullptr; uint32_t* defer_count = nullptr;   // optional queue of the rows with overflow entries (count zeroed by the caller)
+  bool two_pass = false;   // rows with overflow-list entries are handled by a second launch that has LDS room for them
 };
 int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s);
 // exact top-k of a few rows (p.row_ids) against every column, no candidate lists; keys: p.n_rows * p.m floats

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(F_NT, (MODE == MODE_DENSE || CAP <= 16) ? 2 : 1) vo
           key[r] = jv ? key[r] : kNegInf;
           acc[t][r] = 0.0f;
         }
-        if (__builtin_expect(__any(max16(key) >= list.thr), 0)) list.template offer_tile<true>(key, (uint32_t)cand0, half, a.kk, 0.0f);
+        if (__builtin_expect(__any(max16(key) >= list.thr), 0)) list.offer_tile(key, (uint32_t)cand0, half, a.kk);
       }
     }
 
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(F_NT, (MODE == MODE_DENSE || CAP <= 16) ? 2 : 1) vo
   }
 
   if constexpr (MODE == MODE_SCAN) {
-    list.template compact<true>(a.kk, 0.0f);
+    list.compact(a.kk);
     if (qvalid) {
       const int64_t lbase = qpos * (2 * a.col_splits) + 2 * split + half;
       a.cand_cnt[lbase] = (uint32_t)list.cnt;

@@ -27,7 +27,7 @@ struct SelectArgs {
   const uint32_t* spill_cnt; const uint32_t* spill_ids; int spill_cap;   // optional: the row's overflow list
   // staged kernel, two passes when overflow lists exist: pass 0 handles the rows without overflow entries in a lean
   // LDS footprint and queues the others; pass 1 (room for the overflow entries) takes the queue
-  int pass; int32_t* defer_rows; uint32_t* defer_count;
+  int pass; int two_pass;
   int64_t* out_idx; float* out_val;
   int32_t* fail_rows; uint32_t* fail_count; uint32_t* cand_total;
   int maxc;   // staged kernel: candidate slots per wave in dynamic LDS
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
   uint32_t* sid_base = reinterpret_cast<uint32_t*>(skey_base + SEL_WAVES * maxc);
   int64_t pos = (int64_t)blockIdx.x * SEL_WAVES + wave;
   if (pos >= a.n_rows) return;
-  if (a.defer_rows) {
+  if (a.two_pass) {
     // two passes: rows with overflow entries wait for the second launch, which has LDS room for them.  Both launches
     // cover every row and a row decides by its own counters which one it belongs to (a queue filled through one
     // atomic counter cost 25 cycles per row at the L2 when every row has overflow entries, i.e. on clustered data).
@@ -412,11 +412,11 @@ static int launch_select_m(const SelectArgs& a, bool vec4, bool staged16, hipStr
   if ((vec4 || staged16) && a.d >= 64) {
     auto kern = a.dtype == MMF_F32 ? select_staged_kernel<METRIC, MMF_F32>
                 : (a.dtype == MMF_BF16 ? select_staged_kernel<METRIC, MMF_BF16> : select_staged_kernel<METRIC, MMF_F16>);
-    const bool two = a.spill_cnt != nullptr && a.defer_rows != nullptr && a.row_ids == nullptr;
+    const bool two = a.spill_cnt != nullptr && a.two_pass && a.row_ids == nullptr;
     for (int pass = 0; pass < (two ? 2 : 1); ++pass) {
       SelectArgs b = a;
       b.pass = pass;
-      if (!two) b.defer_rows = nullptr;
+      if (!two) b.two_pass = 0;
       const int extra = (two && pass == 0) ? 0 : a.spill_cap;
       b.maxc = ((a.lists * a.cap + extra + 63) / 64) * 64;
       const size_t lds = sizeof(float) * SEL_WAVES * (SG * SLD + SC) + (size_t)SEL_WAVES * b.maxc * 8;
@@ -444,7 +444,7 @@ int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
   a.cand_cnt = L.cnt; a.cand_ids = L.ids; a.overflow = L.overflow; a.lists = L.lists; a.cap = L.cap;
   a.cand_keys = L.keys; a.margin = L.margin; a.slot_ulp = L.slot_ulp;
   a.spill_cnt = L.spill_cnt; a.spill_ids = L.spill_ids; a.spill_cap = L.spill_cap;
-  a.pass = 0; a.defer_rows = p.defer_rows; a.defer_count = p.defer_count;
+  a.pass = 0; a.two_pass = p.two_pass ? 1 : 0;
   a.out_idx = p.out_idx; a.out_val = p.out_val;
   a.fail_rows = p.fail_rows; a.fail_count = p.fail_count; a.cand_total = p.cand_total;
   const bool v4 = p.dtype == MMF_F32 && (p.d % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0) &&
