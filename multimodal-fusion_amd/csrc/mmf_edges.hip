@@ -118,14 +118,10 @@ int launch_offdiag_lower_median(const float* K, int64_t n, float* out, void* scr
 
 // The same radix select in pieces, for matrices that are recomputed panel by panel instead of stored:
 // begin; then for pass 0..3 { accumulate every panel; next }.  `out` is written by next(pass 3).
-size_t median_state_bytes() { return sizeof(MedianState); }
 int launch_median_begin_count(void* state, unsigned long long cnt, hipStream_t s) {
   hipLaunchKernelGGL(median_init_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<MedianState*>(state), (cnt - 1) / 2);
   MMF_LAUNCH_CHECK();
   return MMF_OK;
-}
-int launch_median_begin(void* state, int64_t n, hipStream_t s) {
-  return launch_median_begin_count(state, (unsigned long long)n * (unsigned long long)(n - 1), s);
 }
 int launch_median_accumulate(const float* K, int64_t n, int64_t row0, int64_t rows, void* state, int pass, hipStream_t s) {
   if (rows <= 0) return MMF_OK;
@@ -601,10 +597,6 @@ int launch_stats_set_median(const float* med, double* out, hipStream_t s) {
   return MMF_OK;
 }
 size_t stat_partial_bytes() { return sizeof(StatPartial); }
-// one radix pass over `rows` rows of `cols` values each (a panel of a rectangular matrix: no diagonal to skip)
-int launch_median_accumulate_flat(const float* K, int64_t cols, int64_t rows, void* state, int pass, hipStream_t s) {
-  return launch_median_accumulate(K, cols, kNoDiagonal, rows, state, pass, s);
-}
 
 // ------------------------------------------------------------------------------------------------
 // threshold edges

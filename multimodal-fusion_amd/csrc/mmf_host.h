@@ -184,8 +184,6 @@ int launch_sample_pairs(const void* A, const void* B, int64_t nb, int64_t d, int
 int launch_offdiag_lower_median(const float* K, int64_t n, float* out, void* scratch /* median_scratch_bytes(n (n - 1)) */,
                                 hipStream_t s);
 // the radix select in pieces (matrices recomputed panel by panel): begin; for pass 0..3 { accumulate panels; next }
-size_t median_state_bytes();
-int launch_median_begin(void* state, int64_t n, hipStream_t s);
 int launch_median_accumulate(const float* K, int64_t n, int64_t row0, int64_t rows, void* state, int pass, hipStream_t s);
 int launch_median_next(void* state, int pass, float* out, hipStream_t s);
 int launch_median_begin_count(void* state, unsigned long long count, hipStream_t s);
@@ -194,7 +192,6 @@ int launch_lower_median(const float* v, int64_t count, float* out, void* scratch
 int launch_stats_finish(const void* part, int64_t nparts, const float* pivot, int64_t count, double* out, hipStream_t s);
 int launch_stats_set_median(const float* med, double* out, hipStream_t s);
 size_t stat_partial_bytes();
-int launch_median_accumulate_flat(const float* K, int64_t cols, int64_t rows, void* state, int pass, hipStream_t s);
 // mmf_direct.hip: register-tiled direct-difference RBF with optional per-workgroup statistic partials
 int64_t rbf_direct_blocks(int64_t n, int64_t m);
 int launch_rbf_direct_pivot(const void* X, const void* Y, int64_t d, int dtype, float lambda, float* pivot, hipStream_t s);
