@@ -235,11 +235,12 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_kernel(SelectArgs a) {
 }
 
 // f32, d % 4 == 0: the same selection with the candidate rows staged through LDS.  Per query the wave
-// walks its candidates in groups of 16 and k in chunks of 128: every global read is a coalesced
-// 512-byte row segment (two candidates per wave instruction, eight instructions in flight), and the
+// walks its candidates in groups of SG and k in chunks of 128: every global read is a coalesced
+// 512-byte row segment (two candidates per wave instruction, SG / 2 instructions in flight), and the
 // canonical k-ordered chains run out of LDS (row stride 132 floats: conflict-free ds_read_b128),
-// one lane per candidate.
-constexpr int SG = 16;
+// one lane per candidate.  SG = 8 for the common launch (6.5 candidates per row on Gaussian data: half the LDS, 24
+// instead of 16 waves per CU, re-rank 1.35 -> 1.04 ms at N = 262144), 16 for the launch that takes the rows with
+// overflow-list entries (129 candidates per row on clustered data: fewer group rounds, 11.6 -> 10.7 ms).
 constexpr int SC = 128;
 constexpr int SLD = SC + 4;
 
@@ -262,7 +263,7 @@ __device__ __forceinline__ f32x4 ld4_row(const void* base, int64_t elem) {
   }
 }
 
-template <int METRIC, int DT>
+template <int METRIC, int DT, int SG>
 __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArgs a) {
   // dynamic LDS: per wave [maxc] keys + [maxc] ids (maxc = lists * cap rounded up to 64), then the tiles
   extern __shared__ __attribute__((aligned(16))) char sel_smem[];
@@ -410,8 +411,6 @@ template <int METRIC>
 static int launch_select_m(const SelectArgs& a, bool vec4, bool staged16, hipStream_t s) {
   const int64_t grid = (a.n_rows + SEL_WAVES - 1) / SEL_WAVES;
   if ((vec4 || staged16) && a.d >= 64) {
-    auto kern = a.dtype == MMF_F32 ? select_staged_kernel<METRIC, MMF_F32>
-                : (a.dtype == MMF_BF16 ? select_staged_kernel<METRIC, MMF_BF16> : select_staged_kernel<METRIC, MMF_F16>);
     const bool two = a.spill_cnt != nullptr && a.two_pass && a.row_ids == nullptr;
     for (int pass = 0; pass < (two ? 2 : 1); ++pass) {
       SelectArgs b = a;
@@ -419,7 +418,12 @@ static int launch_select_m(const SelectArgs& a, bool vec4, bool staged16, hipStr
       if (!two) b.two_pass = 0;
       const int extra = (two && pass == 0) ? 0 : a.spill_cap;
       b.maxc = ((a.lists * a.cap + extra + 63) / 64) * 64;
-      const size_t lds = sizeof(float) * SEL_WAVES * (SG * SLD + SC) + (size_t)SEL_WAVES * b.maxc * 8;
+      const int sg = (extra == 0) ? 8 : 16;       // rows with overflow entries carry many candidates
+      auto kern = sg == 8 ? (a.dtype == MMF_F32 ? select_staged_kernel<METRIC, MMF_F32, 8>
+                             : (a.dtype == MMF_BF16 ? select_staged_kernel<METRIC, MMF_BF16, 8> : select_staged_kernel<METRIC, MMF_F16, 8>))
+                          : (a.dtype == MMF_F32 ? select_staged_kernel<METRIC, MMF_F32, 16>
+                             : (a.dtype == MMF_BF16 ? select_staged_kernel<METRIC, MMF_BF16, 16> : select_staged_kernel<METRIC, MMF_F16, 16>));
+      const size_t lds = sizeof(float) * SEL_WAVES * (sg * SLD + SC) + (size_t)SEL_WAVES * b.maxc * 8;
       MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * SEL_WAVES), lds, s, b);
       MMF_LAUNCH_CHECK();

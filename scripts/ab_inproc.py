@@ -39,7 +39,7 @@ def use(name):
         libs[name] = mmf._lib.lib()
 
 
-libs, times, ref = {}, {n: [] for n in a.names}, None
+libs, times, rerank, ref = {}, {n: [] for n in a.names}, {n: [] for n in a.names}, None
 for r in range(a.rounds + 1):
     for n in a.names:
         use(n)
@@ -51,7 +51,9 @@ for r in range(a.rounds + 1):
                 assert torch.equal(i, ref[0]) and torch.equal(v, ref[1]), f"{n}: result differs from {a.names[0]}"
             continue
         times[n].append(st["scan_ms"])
+        rerank[n].append(st["rerank_ms"])
 for n in a.names:
     t = times[n]
     print(f"{n:12s} scan_ms median {statistics.median(t):7.3f}  min {min(t):7.3f}  max {max(t):7.3f}   "
-          f"frac(median) {2.0 * a.rows * a.rows * a.dim / (statistics.median(t) * 1e-3) / 2.5e15:.4f}", flush=True)
+          f"frac(median) {2.0 * a.rows * a.rows * a.dim / (statistics.median(t) * 1e-3) / 2.5e15:.4f}   "
+          f"rerank_ms median {statistics.median(rerank[n]):6.3f}", flush=True)
