@@ -5,7 +5,7 @@ of multimodal-fusion_amd/distributed.py and checks both against the unsharded re
         scripts/rehearse_shards.py
 
 Covers: all four metrics; f32 / f16 / bf16 rows; f16 and bf16 scan operands; gather_output; forced chunk counts and
-column splits; REPEATED calls that land in the same padded exchange buffers with fewer rows, other data and another d
+column splits; near-duplicate rows (overflow lists) and 32-entry lists; REPEATED calls that land in the same padded exchange buffers with fewer rows, other data and another d
 (the buffers are cached between calls, so whatever the gathers do not overwrite must be re-established every time);
 and the event hand-off (panel ready_events and select_wait_event are recorded on the side stream under gloo as well).
 tests/test_gpu_distributed.py runs this under pytest -m gpu."""
@@ -76,6 +76,20 @@ for N, d, seed in ((16384, 512, 11), (16368, 512, 12), (16368, 500, 13), (16384,
     X = rows(N, d, seed, 1.0, torch.float32)
     for metric in ("cosine", "neg_sq_l2"):
         check(X, N, f"repeat N={N} d={d} {metric}", metric=metric, k=5, chunks=2)
+
+# near-duplicate rows (crowded lists: band entries go straight to the overflow lists, which the lanes reserve in chunks
+# and whose ids are mapped from panel columns to global columns) through both drivers, and k + self = 25 (32-entry lists)
+g = torch.Generator(device=dev).manual_seed(21)
+centers = torch.randn((128, 256), generator=g, device=dev)
+centers = centers / centers.norm(dim=1, keepdim=True)
+Xc = centers[torch.randint(0, 128, (16384,), generator=g, device=dev)] + (0.03 / 16.0) * torch.randn((16384, 256), generator=g, device=dev)
+Xc = Xc / Xc.norm(dim=1, keepdim=True)      # 128 clusters of ~128 rows: every row's margin band is its cluster
+st_c = dmod.sharded_simtopk(Xc[dmod.shard_bounds(16384, world, rank)[0]:dmod.shard_bounds(16384, world, rank)[1]].clone(), 16384,
+                            metric="cosine", k=5, chunks=2, return_stats=True)[2]
+assert st_c["candidates"] > 60 * (16384 // world), st_c      # the overflow lists are in use
+check(Xc, 16384, "clustered pipelined", metric="cosine", k=5, chunks=2)
+check(Xc, 16384, "clustered simple", metric="neg_sq_l2", k=5, overlap=False)
+check(Xc, 16384, "clustered k=24", metric="cosine", k=24, chunks=2)
 
 # uneven shards / exact precision take the simple driver
 X = make_rows(0, 8190 + world - 1, 128, dev)
