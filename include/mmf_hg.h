@@ -339,6 +339,18 @@ int mmf_combined_threshold_edges(const float* F, const float* P, int64_t n, int6
  *                             smaller row) or when `labels` (may be NULL) puts both ends in one segment, i.e. a clique
  *                             already holds it.  pair_lo / pair_hi need room for n * k; order unspecified.
  */
+/*
+ * k-means++ seeding for the device KMeans that stands in for the reference's
+ * KMeans(n_clusters, random_state=42, n_init=10).fit_predict (preprocess_hypergraph.py:150-151, 299-300, 391-392):
+ *   out[r][i] = min(closest[r / group][i], |x_i - x_cand[r]|^2)   r < n_cand, i < n
+ * squared distances of every row of X[n, d] (f32) to the candidate rows X[cand[r]] — candidates of several independent
+ * seedings side by side, `group` per seeding — clamped by each seeding's running distance to its closest chosen centre
+ * (closest: [ceil(n_cand / group), n], or NULL for no clamp).  Direct differences, fixed summation tree: deterministic.
+ * d <= 8192.
+ */
+int mmf_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand, int64_t n_cand, int64_t group,
+                       const float* closest, float* out, int device_id, void* hip_stream);
+
 int mmf_segment_sort(const int64_t* labels, int64_t n, int64_t n_segments, int64_t* counts, int64_t* offsets,
                      int64_t* order, int device_id, void* hip_stream);
 int mmf_segment_mean(const float* X, int64_t n, int64_t d, const int64_t* order, const int64_t* offsets,

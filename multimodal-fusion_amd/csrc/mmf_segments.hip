@@ -366,6 +366,81 @@ int launch_knn_pairs(const int64_t* nbr, int64_t n, int k, const int64_t* labels
   return MMF_OK;
 }
 
+// ---- k-means++ seeding ---------------------------------------------------------------------------------------------
+// out[r][i] = min(closest[r / group][i], |x_i - x_cand[r]|^2): squared distances of every row to R candidate rows, clamped by
+// the running distance to the closest centre already chosen (closest == NULL: no clamp).  Direct differences, lanes
+// across k, a fixed butterfly: deterministic.  Workgroup = 64 points x up to 16 candidates (their rows sit in LDS); a wave
+// walks 16 of the points, results go through LDS so that the stores are 64 consecutive points of one candidate.
+constexpr int SD_CH = 16;
+__global__ __launch_bounds__(256) void seed_dists_kernel(const float* __restrict__ X, int64_t n, int64_t d,
+                                                         const int64_t* __restrict__ cand, int64_t n_cand, int64_t group, int ch,
+                                                         const float* __restrict__ closest, float* __restrict__ out) {
+  extern __shared__ float sd_smem[];
+  float* cs = sd_smem;                         // [ch][d]
+  float* res = sd_smem + (size_t)ch * d;       // [ch][64]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * ch;
+  const int nc = (int)((n_cand - r0 < ch) ? (n_cand - r0) : ch);
+  for (int c = 0; c < nc; ++c) {
+    int64_t src = cand[r0 + c];
+    if (src < 0) src = 0;
+    if (src > n - 1) src = n - 1;
+    for (int64_t k = threadIdx.x; k < d; k += 256) cs[(size_t)c * d + k] = X[src * d + k];
+  }
+  __syncthreads();
+  const int64_t i0 = (int64_t)blockIdx.x * 64;
+  for (int p = 0; p < 16; ++p) {
+    const int64_t i = i0 + w * 16 + p;
+    float acc[SD_CH];
+#pragma unroll
+    for (int c = 0; c < SD_CH; ++c) acc[c] = 0.0f;
+    if (i < n) {
+      for (int64_t k = lane; k < d; k += 64) {
+        const float x = X[i * d + k];
+#pragma unroll
+        for (int c = 0; c < SD_CH; ++c) {
+          if (c < nc) { const float t = x - cs[(size_t)c * d + k]; acc[c] = __builtin_fmaf(t, t, acc[c]); }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < SD_CH; ++c) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < SD_CH; ++c)
+        if (c < nc) res[c * 64 + w * 16 + p] = acc[c];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nc * 64; e += 256) {
+    const int c = e >> 6;
+    const int64_t i = i0 + (e & 63);
+    if (i < n) {
+      float v = res[e];
+      if (closest) v = fminf(v, closest[((r0 + c) / group) * n + i]);
+      out[(r0 + c) * n + i] = v;
+    }
+  }
+}
+
+int seed_distances_max_dim() { return 8192; }
+int launch_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand, int64_t n_cand, int64_t group,
+                          const float* closest, float* out, hipStream_t s) {
+  if (n <= 0 || n_cand <= 0) return MMF_OK;
+  int ch = (int)(12288 / d);                   // candidate rows per workgroup: up to 48 KiB of LDS
+  if (ch > SD_CH) ch = SD_CH;
+  if (ch < 1) ch = 1;
+  const size_t lds = ((size_t)ch * d + (size_t)ch * 64) * sizeof(float);
+  MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seed_dists_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n_cand + ch - 1) / ch));
+  hipLaunchKernelGGL(seed_dists_kernel, grid, dim3(256), lds, s, X, n, d, cand, n_cand, group, ch, closest, out);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+
 int segment_max_segments() { return SEG_MAX; }
 
 }  // namespace mmf

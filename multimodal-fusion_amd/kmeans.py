@@ -6,7 +6,8 @@ distance computations that dominate it run on the hot-path kernels of libmmf_hg.
 
 * assignment  = fused similarity + top-1 (``mmf_simtopk``, squared L2, k = 1) of every point against
   the centroids — labels and distances come out of one scan, the N x k matrix is never stored;
-* k-means++    = dense squared-L2 rows of the few candidate centres against all points (``mmf_sim_dense``).
+* k-means++    = squared-distance rows of the trial candidates of all n_init seedings against all points, one kernel
+  per seeding step (``mmf_seed_distances``).
 
 Centroid updates are segmented means in a fixed summation order (``mmf_segment_sort`` + ``mmf_segment_mean``), so the
 whole fit is deterministic: same data and seed, same labels, run after run.  Bit-parity with scikit-learn is not
@@ -28,27 +29,28 @@ def _assign(X: torch.Tensor, C: torch.Tensor) -> Tuple[torch.Tensor, torch.Tenso
     return idx[:, 0], (-val[:, 0]).clamp_min_(0.0)
 
 
-def _sq_dists(A: torch.Tensor, X: torch.Tensor) -> torch.Tensor:
-    return (-ops.sim_dense(A, X, metric="neg_sq_l2")).clamp_min_(0.0)        # [len(A), N]
-
-
-def _kmeanspp(X: torch.Tensor, k: int, gen: torch.Generator) -> torch.Tensor:
-    """Greedy k-means++ (Arthur & Vassilvitskii, with 2 + log k local trials per step)."""
+def _kmeanspp(X: torch.Tensor, k: int, n_init: int, gen: torch.Generator) -> torch.Tensor:
+    """Greedy k-means++ (Arthur & Vassilvitskii, with 2 + log k local trials per step) for ALL n_init seedings in
+    lockstep: step s draws the trial candidates of every seeding, one kernel forms their distance rows clamped by
+    each seeding's running closest-centre distance (``mmf_seed_distances``), and the best trial per seeding is taken
+    on the device — no host round trip inside the k - 1 steps (one seeding at a time with a `.item()` per step was
+    85 % of a fit).  Returns the centres, [n_init, k, D]."""
     n = X.shape[0]
     trials = 2 + int(math.log(k))
-    first = int(torch.randint(n, (1,), generator=gen, device=X.device))
-    centers = [X[first]]
-    closest = _sq_dists(X[first:first + 1], X)[0]
-    pot = closest.sum()
-    for _ in range(1, k):
-        r = torch.rand(trials, generator=gen, device=X.device) * pot
-        cand = torch.searchsorted(torch.cumsum(closest, 0), r).clamp_(max=n - 1)
-        dc = torch.minimum(_sq_dists(X[cand], X), closest[None, :])        # [trials, N]
-        pots = dc.sum(dim=1)
-        best = int(torch.argmin(pots))
-        closest, pot = dc[best], pots[best]
-        centers.append(X[cand[best]])
-    return torch.stack(centers, 0).contiguous()
+    ar = torch.arange(n_init, device=X.device)
+    cidx = torch.empty((n_init, k), dtype=torch.int64, device=X.device)
+    cidx[:, 0] = torch.randint(n, (n_init,), generator=gen, device=X.device)
+    closest = ops.seed_distances(X, cidx[:, 0])                                  # [n_init, N]
+    pot = closest.sum(dim=1)
+    for s in range(1, k):
+        r = torch.rand((n_init, trials), generator=gen, device=X.device) * pot[:, None]
+        cand = torch.searchsorted(torch.cumsum(closest, dim=1), r).clamp_(max=n - 1)          # [n_init, trials]
+        dc = ops.seed_distances(X, cand.reshape(-1), trials, closest).view(n_init, trials, n)
+        pots = dc.sum(dim=2)
+        best = pots.argmin(dim=1)
+        closest, pot = dc[ar, best], pots[ar, best]
+        cidx[:, s] = cand[ar, best]
+    return X[cidx].contiguous()
 
 
 def kmeans_fit_predict(X: torch.Tensor, n_clusters: int, *, n_init: int = 10, max_iter: int = 300,
@@ -65,8 +67,9 @@ def kmeans_fit_predict(X: torch.Tensor, n_clusters: int, *, n_init: int = 10, ma
     tol_abs = float(tol) * float(Xc.var(dim=0, unbiased=False).mean())
     gen = torch.Generator(device=X.device).manual_seed(int(seed))
     best = None
-    for _ in range(n_init):
-        C = _kmeanspp(Xc, n_clusters, gen)
+    seeds = _kmeanspp(Xc, n_clusters, n_init, gen)
+    for init in range(n_init):
+        C = seeds[init]
         labels = None
         for _it in range(max_iter):
             labels, d2 = _assign(Xc, C)

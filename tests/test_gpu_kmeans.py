@@ -58,3 +58,20 @@ def test_mirror_with_device_kmeans_backend():
         pp.set_kmeans_backend(prev)
     # separable blobs: both backends find the same 4 cliques, hence the same edge set and weights
     assert torch.equal(ei_s, ei_d) and torch.equal(ew_s, ew_d) and st_s == st_d
+
+
+@pytest.mark.parametrize("n,d,R,group", [(1, 1, 1, 1), (130, 33, 7, 3), (1000, 512, 60, 6), (257, 1024, 20, 5), (300, 3000, 4, 2)])
+def test_seed_distances_against_torch(n, d, R, group):
+    """mmf_seed_distances: squared distances to the candidate rows, clamped per seeding — against float64 torch."""
+    import multimodal_fusion_amd as mmf
+    g = torch.Generator().manual_seed(n + d)
+    X = torch.randn(n, d, generator=g).cuda()
+    cand = torch.randint(0, n, (R,), generator=g).cuda()
+    closest = torch.rand(-(-R // group), n, generator=g).cuda() * d
+    ref = ((X[cand].double()[:, None, :] - X.double()[None, :, :]) ** 2).sum(-1)
+    out = mmf.ops.seed_distances(X, cand)
+    torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-5)
+    out2 = mmf.ops.seed_distances(X, cand, group, closest)
+    ref2 = torch.minimum(ref, closest.double()[torch.arange(R, device="cuda") // group])
+    torch.testing.assert_close(out2.double(), ref2, rtol=1e-5, atol=1e-5)
+    assert torch.equal(out2, mmf.ops.seed_distances(X, cand, group, closest))      # deterministic
