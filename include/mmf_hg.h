@@ -340,16 +340,17 @@ int mmf_combined_threshold_edges(const float* F, const float* P, int64_t n, int6
  *                             already holds it.  pair_lo / pair_hi need room for n * k; order unspecified.
  */
 /*
- * k-means++ seeding for the device KMeans that stands in for the reference's
+ * The distance rows of the device KMeans that stands in for the reference's
  * KMeans(n_clusters, random_state=42, n_init=10).fit_predict (preprocess_hypergraph.py:150-151, 299-300, 391-392):
- *   out[r][i] = min(closest[r / group][i], |x_i - x_cand[r]|^2)   r < n_cand, i < n
- * squared distances of every row of X[n, d] (f32) to the candidate rows X[cand[r]] — candidates of several independent
- * seedings side by side, `group` per seeding — clamped by each seeding's running distance to its closest chosen centre
- * (closest: [ceil(n_cand / group), n], or NULL for no clamp).  Direct differences, fixed summation tree: deterministic.
- * d <= 8192.
+ *   out[r][i] = min(closest[r / group][i], |x_i - c_r|^2)   r < n_cand, i < n
+ * squared distances of every row of X[n, d] (f32) to n_cand candidate rows c_r: rows of X picked by cand[r]
+ * (k-means++ seeding: the trial candidates of several independent seedings side by side, `group` per seeding, clamped
+ * by each seeding's running distance to its closest chosen centre, closest: [ceil(n_cand / group), n]) or, when
+ * cand_rows != NULL, the rows of that [n_cand, d] matrix (the centroids of all restarts at once: the assignment step;
+ * closest == NULL: no clamp).  Direct differences, fixed summation tree: deterministic.  d <= 32768.
  */
-int mmf_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand, int64_t n_cand, int64_t group,
-                       const float* closest, float* out, int device_id, void* hip_stream);
+int mmf_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
+                       int64_t group, const float* closest, float* out, int device_id, void* hip_stream);
 
 int mmf_segment_sort(const int64_t* labels, int64_t n, int64_t n_segments, int64_t* counts, int64_t* offsets,
                      int64_t* order, int device_id, void* hip_stream);

@@ -86,7 +86,7 @@ def lib() -> ctypes.CDLL:
     L.mmf_segment_offdiag_mean.argtypes = [vp, i64, vp, vp, i64, vp, ci, vp]
     L.mmf_clique_pairs.argtypes = [vp, vp, i64, i64, vp, vp, i64, vp, ci, vp]
     L.mmf_knn_pairs.argtypes = [vp, i64, ci, vp, vp, vp, vp, ci, vp]
-    L.mmf_seed_distances.argtypes = [vp, i64, i64, vp, i64, i64, vp, vp, ci, vp]
+    L.mmf_seed_distances.argtypes = [vp, i64, i64, vp, vp, i64, i64, vp, vp, ci, vp]
     L.mmf_lower_median.argtypes = [vp, i64, vp, ci, vp]
     L.mmf_array_stats.argtypes = [vp, i64, vp, ci, vp]
     L.mmf_threshold_edges.argtypes = [vp, i64, f32, vp, vp, i64, vp, ci, vp]

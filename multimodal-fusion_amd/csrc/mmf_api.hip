@@ -968,15 +968,15 @@ int mmf_knn_pairs(const int64_t* nbr, int64_t n, int k, const int64_t* labels, i
   return launch_knn_pairs(nbr, n, k, labels, pair_lo, pair_hi, out_count, static_cast<hipStream_t>(hip_stream));
 }
 
-int mmf_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand, int64_t n_cand, int64_t group,
-                       const float* closest, float* out, int device_id, void* hip_stream) {
+int mmf_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
+                       int64_t group, const float* closest, float* out, int device_id, void* hip_stream) {
   if (device_id < 0) { set_error("seed_distances: no CPU path"); return MMF_E_UNSUPPORTED; }
   if (n < 0 || d < 1 || n_cand < 0 || group < 1) { set_error("seed_distances: bad n / d / n_cand / group"); return MMF_E_INVALID; }
   if (d > seed_distances_max_dim()) { set_error("seed_distances: d = %lld above the supported %d", (long long)d, seed_distances_max_dim()); return MMF_E_UNSUPPORTED; }
-  if (n > 0 && n_cand > 0 && (!X || !cand || !out)) { set_error("seed_distances: NULL pointer"); return MMF_E_INVALID; }
+  if (n > 0 && n_cand > 0 && (!X || (!cand && !cand_rows) || !out)) { set_error("seed_distances: NULL pointer"); return MMF_E_INVALID; }
   DeviceGuard guard(device_id);
   if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
-  return launch_seed_distances(X, n, d, cand, n_cand, group, closest, out, static_cast<hipStream_t>(hip_stream));
+  return launch_seed_distances(X, n, d, cand, cand_rows, n_cand, group, closest, out, static_cast<hipStream_t>(hip_stream));
 }
 
 int mmf_lower_median(const float* v, int64_t count, float* out_median, int device_id, void* hip_stream) {

@@ -367,13 +367,15 @@ int launch_knn_pairs(const int64_t* nbr, int64_t n, int k, const int64_t* labels
 }
 
 // ---- k-means++ seeding ---------------------------------------------------------------------------------------------
-// out[r][i] = min(closest[r / group][i], |x_i - x_cand[r]|^2): squared distances of every row to R candidate rows, clamped by
+// out[r][i] = min(closest[r / group][i], |x_i - c_r|^2): squared distances of every row to R candidate rows — rows of X picked
+// by index (seeding), or an explicit [R, d] matrix (the centroids of all restarts: the assignment step) — clamped by
 // the running distance to the closest centre already chosen (closest == NULL: no clamp).  Direct differences, lanes
 // across k, a fixed butterfly: deterministic.  Workgroup = 64 points x up to 16 candidates (their rows sit in LDS); a wave
 // walks 16 of the points, results go through LDS so that the stores are 64 consecutive points of one candidate.
 constexpr int SD_CH = 16;
 __global__ __launch_bounds__(256) void seed_dists_kernel(const float* __restrict__ X, int64_t n, int64_t d,
-                                                         const int64_t* __restrict__ cand, int64_t n_cand, int64_t group, int ch,
+                                                         const int64_t* __restrict__ cand, const float* __restrict__ cand_rows,
+                                                         int64_t n_cand, int64_t group, int ch,
                                                          const float* __restrict__ closest, float* __restrict__ out) {
   extern __shared__ float sd_smem[];
   float* cs = sd_smem;                         // [ch][d]
@@ -382,10 +384,15 @@ __global__ __launch_bounds__(256) void seed_dists_kernel(const float* __restrict
   const int64_t r0 = (int64_t)blockIdx.y * ch;
   const int nc = (int)((n_cand - r0 < ch) ? (n_cand - r0) : ch);
   for (int c = 0; c < nc; ++c) {
-    int64_t src = cand[r0 + c];
-    if (src < 0) src = 0;
-    if (src > n - 1) src = n - 1;
-    for (int64_t k = threadIdx.x; k < d; k += 256) cs[(size_t)c * d + k] = X[src * d + k];
+    const float* row;
+    if (cand_rows) row = cand_rows + (r0 + c) * d;           // explicit candidate rows (centroids)
+    else {
+      int64_t src = cand[r0 + c];
+      if (src < 0) src = 0;
+      if (src > n - 1) src = n - 1;
+      row = X + src * d;
+    }
+    for (int64_t k = threadIdx.x; k < d; k += 256) cs[(size_t)c * d + k] = row[k];
   }
   __syncthreads();
   const int64_t i0 = (int64_t)blockIdx.x * 64;
@@ -426,9 +433,9 @@ __global__ __launch_bounds__(256) void seed_dists_kernel(const float* __restrict
   }
 }
 
-int seed_distances_max_dim() { return 8192; }
-int launch_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand, int64_t n_cand, int64_t group,
-                          const float* closest, float* out, hipStream_t s) {
+int seed_distances_max_dim() { return 32768; }
+int launch_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
+                          int64_t group, const float* closest, float* out, hipStream_t s) {
   if (n <= 0 || n_cand <= 0) return MMF_OK;
   int ch = (int)(12288 / d);                   // candidate rows per workgroup: up to 48 KiB of LDS
   if (ch > SD_CH) ch = SD_CH;
@@ -436,7 +443,7 @@ int launch_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* c
   const size_t lds = ((size_t)ch * d + (size_t)ch * 64) * sizeof(float);
   MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seed_dists_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n_cand + ch - 1) / ch));
-  hipLaunchKernelGGL(seed_dists_kernel, grid, dim3(256), lds, s, X, n, d, cand, n_cand, group, ch, closest, out);
+  hipLaunchKernelGGL(seed_dists_kernel, grid, dim3(256), lds, s, X, n, d, cand, cand_rows, n_cand, group, ch, closest, out);
   MMF_LAUNCH_CHECK();
   return MMF_OK;
 }

@@ -66,9 +66,57 @@ def kmeans_fit_predict(X: torch.Tensor, n_clusters: int, *, n_init: int = 10, ma
     Xc = X - mean                                                             # as sklearn: better conditioned
     tol_abs = float(tol) * float(Xc.var(dim=0, unbiased=False).mean())
     gen = torch.Generator(device=X.device).manual_seed(int(seed))
+    C = _kmeanspp(Xc, n_clusters, n_init, gen)                                # [n_init, k, D]
+    # lockstep pays while the [n_init * k, N] distance rows are small (measured: N = 16384, k = 100: 43 -> 36 ms per fit,
+    # 10 groups of 100 rows: 8 -> 2 ms; N = 65536: 112 -> 150 ms, so large problems go restart by restart)
+    if n_init * n_clusters <= 16384 and n_init * n_clusters * n <= (1 << 24):
+        labels, C, inertia = _lloyd_lockstep(Xc, C, max_iter, tol_abs)
+    else:
+        labels, C, inertia = _lloyd_one_by_one(Xc, C, max_iter, tol_abs)
+    return labels, C + mean, inertia
+
+
+def _lloyd_lockstep(Xc: torch.Tensor, C: torch.Tensor, max_iter: int, tol_abs: float):
+    """All restarts iterate together: one kernel forms the distance rows of every restart's centroids
+    (``mmf_seed_distances`` with explicit rows), one counting sort groups the members of all n_init * k clusters, one
+    segmented mean updates all centroids — a dozen launches and two host round trips per iteration for ALL restarts
+    (one restart at a time: that many per restart).  A restart that has converged keeps iterating at its fixed point
+    until the last one has."""
+    I, k, d = C.shape
+    n = Xc.shape[0]
+    base = (torch.arange(I, device=Xc.device) * k)[:, None]
+    def assign(C):
+        D = ops.seed_distances(Xc, C.reshape(I * k, d)).view(I, k, n)
+        d2, lab = D.min(dim=1)                                                # [I, n]
+        return lab, d2
+    for _it in range(max_iter):
+        lab, d2 = assign(C)
+        seg = ops.segment_sort((lab + base).reshape(-1), I * k)               # members of all I * k clusters
+        rows = ops.Segments(seg.counts, seg.offsets, seg.order % n, n, I * k)
+        newC = ops.segment_mean(Xc, rows).view(I, k, d)
+        empty = (seg.counts == 0).view(I, k)
+        shift = ((newC - C) ** 2).sum(dim=(1, 2))
+        any_empty, done = torch.stack([empty.any(), (shift <= tol_abs).all()]).tolist()
+        if any_empty:                                                         # relocate empty clusters to the points
+            for i in torch.nonzero(empty.any(dim=1)).flatten().tolist():      # farthest from their centre
+                far = torch.topk(d2[i], int(empty[i].sum())).indices
+                newC[i][empty[i]] = Xc[far]
+            done = False
+        C = newC
+        if done:
+            break
+    lab, d2 = assign(C)
+    inertia = d2.sum(dim=1)
+    best = int(torch.argmin(inertia))
+    return lab[best].contiguous(), C[best], float(inertia[best])
+
+
+def _lloyd_one_by_one(Xc: torch.Tensor, seeds: torch.Tensor, max_iter: int, tol_abs: float):
+    """Large problems: one restart at a time, assignment by the fused similarity + top-1 scan, which never stores the
+    N x k matrix (and stops each restart at its own convergence)."""
+    n_clusters = seeds.shape[1]
     best = None
-    seeds = _kmeanspp(Xc, n_clusters, n_init, gen)
-    for init in range(n_init):
+    for init in range(seeds.shape[0]):
         C = seeds[init]
         labels = None
         for _it in range(max_iter):
@@ -86,5 +134,5 @@ def kmeans_fit_predict(X: torch.Tensor, n_clusters: int, *, n_init: int = 10, ma
         labels, d2 = _assign(Xc, C)
         inertia = float(d2.sum())
         if best is None or inertia < best[2]:
-            best = (labels, C + mean, inertia)
+            best = (labels, C, inertia)
     return best

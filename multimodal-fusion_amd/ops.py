@@ -443,18 +443,26 @@ def knn_pairs(nbr: torch.Tensor, labels: Optional[torch.Tensor] = None) -> Tuple
 
 
 def seed_distances(X: torch.Tensor, cand: torch.Tensor, group: int = 1, closest: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[r, i] = min(closest[r // group, i], |x_i - x_cand[r]|^2): the distance rows of k-means++ seeding, candidates of
-    several independent seedings side by side (mmf_seed_distances).  X f32 [n, d]; cand int64 [R]; returns f32 [R, n]."""
+    """out[r, i] = min(closest[r // group, i], |x_i - c_r|^2) (mmf_seed_distances).  X f32 [n, d].  cand: int64 [R] row
+    indices into X (k-means++ seeding: the trial candidates of several independent seedings side by side) or a float
+    [R, d] matrix of explicit rows (the centroids of all restarts: the assignment step).  Returns f32 [R, n]."""
     X = _feat(X, "seed_distances X").float()
     _need_gpu(X, "seed_distances")
-    cand = cand.to(device=X.device, dtype=torch.int64).contiguous()
-    R, n = cand.numel(), X.shape[0]
+    n = X.shape[0]
+    if cand.is_floating_point():
+        rows = _feat(cand.to(X.device), "seed_distances candidate rows").float()
+        if rows.shape[1] != X.shape[1]:
+            raise ValueError("seed_distances: candidate rows must have X's feature dimension")
+        idx, R = None, rows.shape[0]
+    else:
+        idx, rows = cand.to(device=X.device, dtype=torch.int64).contiguous(), None
+        R = idx.numel()
     if closest is not None:
         closest = closest.to(device=X.device, dtype=torch.float32).contiguous()
         if closest.shape != (-(-R // int(group)), n):
             raise ValueError("seed_distances: closest must be [ceil(R / group), n]")
     out = torch.empty((R, n), dtype=torch.float32, device=X.device)
-    rc = _lib.lib().mmf_seed_distances(_p(X), n, X.shape[1], _p(cand), R, int(group), _p(closest), _p(out),
+    rc = _lib.lib().mmf_seed_distances(_p(X), n, X.shape[1], _p(idx), _p(rows), R, int(group), _p(closest), _p(out),
                                        X.device.index or 0, _stream(X.device))
     _lib.check(rc, "mmf_seed_distances")
     return out

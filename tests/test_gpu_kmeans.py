@@ -75,3 +75,7 @@ def test_seed_distances_against_torch(n, d, R, group):
     ref2 = torch.minimum(ref, closest.double()[torch.arange(R, device="cuda") // group])
     torch.testing.assert_close(out2.double(), ref2, rtol=1e-5, atol=1e-5)
     assert torch.equal(out2, mmf.ops.seed_distances(X, cand, group, closest))      # deterministic
+    rows = torch.randn(R, d, generator=g).cuda()                                   # explicit candidate rows (centroids)
+    out3 = mmf.ops.seed_distances(X, rows)
+    ref3 = ((rows.double()[:, None, :] - X.double()[None, :, :]) ** 2).sum(-1)
+    torch.testing.assert_close(out3.double(), ref3, rtol=1e-5, atol=1e-5)
