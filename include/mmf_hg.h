@@ -352,6 +352,18 @@ int mmf_combined_threshold_edges(const float* F, const float* P, int64_t n, int6
 int mmf_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
                        int64_t group, const float* closest, float* out, int device_id, void* hip_stream);
 
+/*
+ * Greedy k-means++ seeding (Arthur & Vassilvitskii, `trials` candidates per step, the best one kept) for n_init
+ * independent seedings in lockstep — the initialisation of the same KMeans calls.  The caller supplies the randomness:
+ * u_first[n_init] and u_steps[k - 1][n_init][trials], uniforms in [0, 1) (device f32).  Step s draws every seeding's
+ * trial candidates with probability proportional to its running closest-centre distance (inverse-CDF sampling, f64
+ * sums in a fixed order), forms their clamped distance rows and potentials, and keeps the trial with the smallest
+ * potential: three launches per step, all k - 1 steps enqueued by this one call, nothing returns to the host.
+ * centre_idx[n_init][k] (device int64): the rows of X chosen as initial centres.  Deterministic.  d <= 32768.
+ */
+int mmf_kmeanspp_seed(const float* X, int64_t n, int64_t d, int64_t k, int64_t n_init, int trials, const float* u_first,
+                      const float* u_steps, int64_t* centre_idx, int device_id, void* hip_stream);
+
 int mmf_segment_sort(const int64_t* labels, int64_t n, int64_t n_segments, int64_t* counts, int64_t* offsets,
                      int64_t* order, int device_id, void* hip_stream);
 int mmf_segment_mean(const float* X, int64_t n, int64_t d, const int64_t* order, const int64_t* offsets,

@@ -979,6 +979,25 @@ int mmf_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand
   return launch_seed_distances(X, n, d, cand, cand_rows, n_cand, group, closest, out, static_cast<hipStream_t>(hip_stream));
 }
 
+int mmf_kmeanspp_seed(const float* X, int64_t n, int64_t d, int64_t k, int64_t n_init, int trials, const float* u_first,
+                      const float* u_steps, int64_t* centre_idx, int device_id, void* hip_stream) {
+  if (device_id < 0) { set_error("kmeanspp_seed: no CPU path"); return MMF_E_UNSUPPORTED; }
+  if (n < 1 || d < 1 || k < 1 || k > n || n_init < 1 || trials < 1 || trials > 1024) {
+    set_error("kmeanspp_seed: need 1 <= k <= n, n_init >= 1, 1 <= trials <= 1024 (n = %lld, k = %lld, n_init = %lld, trials = %d)",
+              (long long)n, (long long)k, (long long)n_init, trials);
+    return MMF_E_INVALID;
+  }
+  if (d > seed_distances_max_dim()) { set_error("kmeanspp_seed: d = %lld above the supported %d", (long long)d, seed_distances_max_dim()); return MMF_E_UNSUPPORTED; }
+  if (!X || !u_first || (k > 1 && !u_steps) || !centre_idx) { set_error("kmeanspp_seed: NULL pointer"); return MMF_E_INVALID; }
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  const size_t need = kmeanspp_scratch_bytes(n, n_init, trials);
+  Workspace ws;
+  MMF_TRY(get_workspace(device_id, s, ws_bytes(need, 1), &ws));
+  return launch_kmeanspp(X, n, d, k, n_init, trials, u_first, u_steps, centre_idx, ws.take<char>(need), s);
+}
+
 int mmf_lower_median(const float* v, int64_t count, float* out_median, int device_id, void* hip_stream) {
   if (device_id < 0) { set_error("lower_median: no CPU path"); return MMF_E_UNSUPPORTED; }
   if (count < 1) { set_error("lower_median: need count >= 1 (got %lld)", (long long)count); return MMF_E_INVALID; }

@@ -221,6 +221,9 @@ int launch_clique_pairs(const int64_t* order, const int64_t* offsets, int64_t n,
 int seed_distances_max_dim();
 int launch_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
                           int64_t group, const float* closest, float* out, hipStream_t s);
+size_t kmeanspp_scratch_bytes(int64_t n, int64_t n_init, int trials);
+int launch_kmeanspp(const float* X, int64_t n, int64_t d, int64_t k, int64_t n_init, int trials, const float* U0, const float* U,
+                    int64_t* cidx, void* scratch, hipStream_t s);
 int launch_knn_pairs(const int64_t* nbr, int64_t n, int k, const int64_t* labels, int64_t* lo, int64_t* hi, int64_t* out_count,
                      hipStream_t s);
 

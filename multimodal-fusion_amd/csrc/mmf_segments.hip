@@ -376,7 +376,8 @@ constexpr int SD_CH = 16;
 __global__ __launch_bounds__(256) void seed_dists_kernel(const float* __restrict__ X, int64_t n, int64_t d,
                                                          const int64_t* __restrict__ cand, const float* __restrict__ cand_rows,
                                                          int64_t n_cand, int64_t group, int ch,
-                                                         const float* __restrict__ closest, float* __restrict__ out) {
+                                                         const float* __restrict__ closest, float* __restrict__ out,
+                                                         double* __restrict__ partial) {
   extern __shared__ float sd_smem[];
   float* cs = sd_smem;                         // [ch][d]
   float* res = sd_smem + (size_t)ch * d;       // [ch][64]
@@ -425,17 +426,116 @@ __global__ __launch_bounds__(256) void seed_dists_kernel(const float* __restrict
   for (int e = threadIdx.x; e < nc * 64; e += 256) {
     const int c = e >> 6;
     const int64_t i = i0 + (e & 63);
+    float v = 0.0f;
     if (i < n) {
-      float v = res[e];
+      v = res[e];
       if (closest) v = fminf(v, closest[((r0 + c) / group) * n + i]);
       out[(r0 + c) * n + i] = v;
+    }
+    res[e] = v;
+  }
+  if (partial) {                               // potential of every candidate: this workgroup's 64 points, summed in order
+    __syncthreads();
+    if ((int)threadIdx.x < nc) {
+      double sum = 0.0;
+      for (int q = 0; q < 64; ++q) sum += (double)res[threadIdx.x * 64 + q];
+      partial[(r0 + threadIdx.x) * (int64_t)gridDim.x + blockIdx.x] = sum;
     }
   }
 }
 
+// One workgroup per seeding: draw `trials` candidates with probability proportional to the running closest-centre
+// distance (inverse-CDF sampling: a thread owns a run of consecutive points, the 1024 run totals are scanned in LDS, a
+// uniform lands in a run by binary search and at a point by walking the run).  f64 sums, fixed order: deterministic.
+__global__ __launch_bounds__(1024) void seed_draw_kernel(const float* __restrict__ closest, int64_t n, const float* __restrict__ U,
+                                                         int trials, int64_t* __restrict__ cand) {
+  __shared__ double part[1024];
+  const int t = threadIdx.x;
+  const float* cl = closest + (int64_t)blockIdx.x * n;
+  const int64_t per = (n + 1023) / 1024, b = (int64_t)t * per;
+  int64_t e = b + per;
+  if (e > n) e = n;
+  double sum = 0.0;
+  for (int64_t j = b; j < e; ++j) sum += (double)cl[j];
+  part[t] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const double v = (t >= o) ? part[t - o] : 0.0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  if (t < trials) {
+    const double target = (double)U[(int64_t)blockIdx.x * trials + t] * part[1023];
+    int lo = 0, hi = 1023;                      // first run whose inclusive total reaches the target
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (part[mid] >= target) hi = mid; else lo = mid + 1;
+    }
+    double run = lo ? part[lo - 1] : 0.0;
+    int64_t j = (int64_t)lo * per, last = j + per;
+    if (last > n) last = n;
+    int64_t pick = (last > 0) ? last - 1 : 0;
+    for (; j < last; ++j) {
+      run += (double)cl[j];
+      if (run >= target) { pick = j; break; }
+    }
+    if (pick > n - 1) pick = n - 1;
+    cand[(int64_t)blockIdx.x * trials + t] = pick;
+  }
+}
+
+// One workgroup per seeding: the trial with the smallest potential becomes the next centre; its clamped distance row
+// becomes the seeding's running closest-centre distance.
+__global__ __launch_bounds__(256) void seed_choose_kernel(const float* __restrict__ dc, const double* __restrict__ partial, int64_t nblk,
+                                                          int64_t n, int trials, const int64_t* __restrict__ cand,
+                                                          float* __restrict__ closest, int64_t* __restrict__ cidx, int64_t k, int64_t step) {
+  __shared__ double red[256];
+  __shared__ int best_s;
+  __shared__ double best_pot;
+  const int t = threadIdx.x;
+  const int64_t i = blockIdx.x;
+  for (int tr = 0; tr < trials; ++tr) {
+    const double* p = partial + (i * trials + tr) * nblk;
+    double sum = 0.0;
+    for (int64_t q = t; q < nblk; q += 256) sum += p[q];
+    red[t] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (t < o) red[t] += red[t + o];
+      __syncthreads();
+    }
+    if (t == 0 && (tr == 0 || red[0] < best_pot)) { best_pot = red[0]; best_s = tr; }
+    __syncthreads();
+  }
+  const int bs = best_s;
+  const float* src = dc + (i * trials + bs) * n;
+  float* dst = closest + i * n;
+  for (int64_t j = t; j < n; j += 256) dst[j] = src[j];
+  if (t == 0) cidx[i * k + step] = cand[i * trials + bs];
+}
+
+// first centre of every seeding: a uniform index
+__global__ void seed_first_kernel(const float* __restrict__ U0, int64_t n, int64_t n_init, int64_t k, int64_t* __restrict__ cidx,
+                                  int64_t* __restrict__ cand) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_init) return;
+  int64_t j = (int64_t)((double)U0[i] * (double)n);
+  if (j > n - 1) j = n - 1;
+  if (j < 0) j = 0;
+  cidx[i * k] = j;
+  cand[i] = j;
+}
+
 int seed_distances_max_dim() { return 32768; }
+static int launch_seed_distances_p(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
+                                   int64_t group, const float* closest, float* out, double* partial, hipStream_t s);
 int launch_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
                           int64_t group, const float* closest, float* out, hipStream_t s) {
+  return launch_seed_distances_p(X, n, d, cand, cand_rows, n_cand, group, closest, out, nullptr, s);
+}
+static int launch_seed_distances_p(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
+                                   int64_t group, const float* closest, float* out, double* partial, hipStream_t s) {
   if (n <= 0 || n_cand <= 0) return MMF_OK;
   int ch = (int)(12288 / d);                   // candidate rows per workgroup: up to 48 KiB of LDS
   if (ch > SD_CH) ch = SD_CH;
@@ -443,8 +543,37 @@ int launch_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* c
   const size_t lds = ((size_t)ch * d + (size_t)ch * 64) * sizeof(float);
   MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seed_dists_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n_cand + ch - 1) / ch));
-  hipLaunchKernelGGL(seed_dists_kernel, grid, dim3(256), lds, s, X, n, d, cand, cand_rows, n_cand, group, ch, closest, out);
+  hipLaunchKernelGGL(seed_dists_kernel, grid, dim3(256), lds, s, X, n, d, cand, cand_rows, n_cand, group, ch, closest, out, partial);
   MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+
+// k-means++ for n_init seedings in lockstep, all k - 1 steps enqueued by this one call (three launches per step).
+// U0 [n_init], U [k - 1][n_init][trials]: uniforms in [0, 1).  scratch: kmeanspp_scratch_bytes.
+size_t kmeanspp_scratch_bytes(int64_t n, int64_t n_init, int trials) {
+  const size_t R = (size_t)n_init * trials, nblk = (size_t)((n + 63) / 64);
+  return ((R * n * 4 + 255) & ~size_t(255)) + (((size_t)n_init * n * 4 + 255) & ~size_t(255)) + ((R * nblk * 8 + 255) & ~size_t(255)) +
+         ((R * 8 + 255) & ~size_t(255)) + 256;
+}
+int launch_kmeanspp(const float* X, int64_t n, int64_t d, int64_t k, int64_t n_init, int trials, const float* U0, const float* U,
+                    int64_t* cidx, void* scratch, hipStream_t s) {
+  const size_t R = (size_t)n_init * trials, nblk = (size_t)((n + 63) / 64);
+  char* p = static_cast<char*>(scratch);
+  float* dc = reinterpret_cast<float*>(p); p += (R * n * 4 + 255) & ~size_t(255);
+  float* closest = reinterpret_cast<float*>(p); p += ((size_t)n_init * n * 4 + 255) & ~size_t(255);
+  double* partial = reinterpret_cast<double*>(p); p += (R * nblk * 8 + 255) & ~size_t(255);
+  int64_t* cand = reinterpret_cast<int64_t*>(p);
+  hipLaunchKernelGGL(seed_first_kernel, dim3((unsigned)((n_init + 63) / 64)), dim3(64), 0, s, U0, n, n_init, k, cidx, cand);
+  MMF_LAUNCH_CHECK();
+  MMF_TRY(launch_seed_distances_p(X, n, d, cand, nullptr, n_init, 1, nullptr, closest, nullptr, s));
+  for (int64_t step = 1; step < k; ++step) {
+    hipLaunchKernelGGL(seed_draw_kernel, dim3((unsigned)n_init), dim3(1024), 0, s, closest, n, U + (step - 1) * n_init * trials, trials, cand);
+    MMF_LAUNCH_CHECK();
+    MMF_TRY(launch_seed_distances_p(X, n, d, cand, nullptr, (int64_t)R, trials, closest, dc, partial, s));
+    hipLaunchKernelGGL(seed_choose_kernel, dim3((unsigned)n_init), dim3(256), 0, s, dc, partial, (int64_t)nblk, n, trials, cand, closest,
+                       cidx, k, step);
+    MMF_LAUNCH_CHECK();
+  }
   return MMF_OK;
 }
 

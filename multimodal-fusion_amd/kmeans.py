@@ -6,8 +6,8 @@ distance computations that dominate it run on the hot-path kernels of libmmf_hg.
 
 * assignment  = fused similarity + top-1 (``mmf_simtopk``, squared L2, k = 1) of every point against
   the centroids — labels and distances come out of one scan, the N x k matrix is never stored;
-* k-means++    = squared-distance rows of the trial candidates of all n_init seedings against all points, one kernel
-  per seeding step (``mmf_seed_distances``).
+* k-means++    = all n_init seedings in lockstep inside the library (``mmf_kmeanspp_seed``: draw, distance rows,
+  choice — three launches per seeding step, no host round trip).
 
 Centroid updates are segmented means in a fixed summation order (``mmf_segment_sort`` + ``mmf_segment_mean``), so the
 whole fit is deterministic: same data and seed, same labels, run after run.  Bit-parity with scikit-learn is not
@@ -31,26 +31,15 @@ def _assign(X: torch.Tensor, C: torch.Tensor) -> Tuple[torch.Tensor, torch.Tenso
 
 def _kmeanspp(X: torch.Tensor, k: int, n_init: int, gen: torch.Generator) -> torch.Tensor:
     """Greedy k-means++ (Arthur & Vassilvitskii, with 2 + log k local trials per step) for ALL n_init seedings in
-    lockstep: step s draws the trial candidates of every seeding, one kernel forms their distance rows clamped by
-    each seeding's running closest-centre distance (``mmf_seed_distances``), and the best trial per seeding is taken
-    on the device — no host round trip inside the k - 1 steps (one seeding at a time with a `.item()` per step was
-    85 % of a fit).  Returns the centres, [n_init, k, D]."""
-    n = X.shape[0]
+    lockstep, inside the library (``mmf_kmeanspp_seed``): per step one kernel draws every seeding's trial candidates, one
+    forms their clamped distance rows and potentials, one keeps the best trial — the k - 1 steps are enqueued by a single
+    call and nothing returns to the host (one seeding at a time with a `.item()` per step was 85 % of a fit; the same
+    lockstep in a dozen torch ops per step was still launch-bound: 22 ms at N = 16384).  The uniforms come from the
+    caller's generator.  Returns the centres, [n_init, k, D]."""
     trials = 2 + int(math.log(k))
-    ar = torch.arange(n_init, device=X.device)
-    cidx = torch.empty((n_init, k), dtype=torch.int64, device=X.device)
-    cidx[:, 0] = torch.randint(n, (n_init,), generator=gen, device=X.device)
-    closest = ops.seed_distances(X, cidx[:, 0])                                  # [n_init, N]
-    pot = closest.sum(dim=1)
-    for s in range(1, k):
-        r = torch.rand((n_init, trials), generator=gen, device=X.device) * pot[:, None]
-        cand = torch.searchsorted(torch.cumsum(closest, dim=1), r).clamp_(max=n - 1)          # [n_init, trials]
-        dc = ops.seed_distances(X, cand.reshape(-1), trials, closest).view(n_init, trials, n)
-        pots = dc.sum(dim=2)
-        best = pots.argmin(dim=1)
-        closest, pot = dc[ar, best], pots[ar, best]
-        cidx[:, s] = cand[ar, best]
-    return X[cidx].contiguous()
+    u_first = torch.rand(n_init, generator=gen, device=X.device)
+    u_steps = torch.rand((k - 1, n_init, trials), generator=gen, device=X.device)
+    return X[ops.kmeanspp_seed(X, k, u_first, u_steps)].contiguous()
 
 
 def kmeans_fit_predict(X: torch.Tensor, n_clusters: int, *, n_init: int = 10, max_iter: int = 300,

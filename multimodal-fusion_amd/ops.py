@@ -466,3 +466,21 @@ def seed_distances(X: torch.Tensor, cand: torch.Tensor, group: int = 1, closest:
                                        X.device.index or 0, _stream(X.device))
     _lib.check(rc, "mmf_seed_distances")
     return out
+
+
+def kmeanspp_seed(X: torch.Tensor, k: int, u_first: torch.Tensor, u_steps: torch.Tensor) -> torch.Tensor:
+    """Initial centres of n_init k-means++ seedings in lockstep (mmf_kmeanspp_seed): u_first [n_init] and
+    u_steps [k - 1, n_init, trials] are the caller's uniforms in [0, 1).  Returns int64 [n_init, k] row indices of X."""
+    X = _feat(X, "kmeanspp_seed X").float()
+    _need_gpu(X, "kmeanspp_seed")
+    n_init = u_first.numel()
+    u_first = u_first.to(device=X.device, dtype=torch.float32).contiguous()
+    u_steps = u_steps.to(device=X.device, dtype=torch.float32).contiguous()
+    if k > 1 and (u_steps.dim() != 3 or u_steps.shape[0] != k - 1 or u_steps.shape[1] != n_init):
+        raise ValueError("kmeanspp_seed: u_steps must be [k - 1, n_init, trials]")
+    trials = int(u_steps.shape[2]) if k > 1 else 1
+    out = torch.empty((n_init, int(k)), dtype=torch.int64, device=X.device)
+    rc = _lib.lib().mmf_kmeanspp_seed(_p(X), X.shape[0], X.shape[1], int(k), n_init, trials, _p(u_first), _p(u_steps), _p(out),
+                                      X.device.index or 0, _stream(X.device))
+    _lib.check(rc, "mmf_kmeanspp_seed")
+    return out

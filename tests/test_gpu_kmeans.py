@@ -79,3 +79,39 @@ def test_seed_distances_against_torch(n, d, R, group):
     out3 = mmf.ops.seed_distances(X, rows)
     ref3 = ((rows.double()[:, None, :] - X.double()[None, :, :]) ** 2).sum(-1)
     torch.testing.assert_close(out3.double(), ref3, rtol=1e-5, atol=1e-5)
+
+
+def test_kmeanspp_seed_follows_its_definition():
+    """mmf_kmeanspp_seed against a float64 torch transcription driven by the same uniforms: same centres, step by step
+    (inverse-CDF draws proportional to the running closest-centre distance, best of `trials` by potential)."""
+    import multimodal_fusion_amd as mmf
+    g = torch.Generator().manual_seed(3)
+    n, d, k, n_init, trials = 700, 24, 9, 4, 3
+    X = torch.randn(n, d, generator=g).cuda()
+    u0 = torch.rand(n_init, generator=g).cuda()
+    us = torch.rand(k - 1, n_init, trials, generator=g).cuda()
+    got = mmf.ops.kmeanspp_seed(X, k, u0, us)
+    assert torch.equal(got, mmf.ops.kmeanspp_seed(X, k, u0, us))                   # deterministic
+    Xd = X.double()
+    for i in range(n_init):
+        first = min(int(float(u0[i]) * n), n - 1)
+        assert int(got[i, 0]) == first
+        closest = ((Xd - Xd[first]) ** 2).sum(1)
+        for s in range(1, k):
+            cs = torch.cumsum(closest, 0)
+            best, best_pot, best_row = None, None, None
+            for t in range(trials):
+                target = float(us[s - 1, i, t]) * float(cs[-1])
+                j = min(int(torch.searchsorted(cs, torch.tensor(target, dtype=torch.float64, device="cuda"))), n - 1)
+                row = torch.minimum(closest, ((Xd - Xd[j]) ** 2).sum(1))
+                pot = float(row.sum())
+                if best is None or pot < best_pot:
+                    best, best_pot, best_row = j, pot, row
+            # a draw that lands within rounding of a boundary may pick a neighbour: accept the kernel's pick if its
+            # potential is the same to f32 accuracy
+            gi = int(got[i, s])
+            if gi != best:
+                alt = torch.minimum(closest, ((Xd - Xd[gi]) ** 2).sum(1))
+                assert abs(float(alt.sum()) - best_pot) <= 1e-4 * best_pot, (i, s, gi, best)
+                best_row = alt
+            closest = best_row
