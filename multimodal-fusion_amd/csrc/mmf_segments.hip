@@ -369,8 +369,8 @@ int launch_knn_pairs(const int64_t* nbr, int64_t n, int k, const int64_t* labels
 // ---- k-means++ seeding ---------------------------------------------------------------------------------------------
 // out[r][i] = min(closest[r / group][i], |x_i - c_r|^2): squared distances of every row to R candidate rows — rows of X picked
 // by index (seeding), or an explicit [R, d] matrix (the centroids of all restarts: the assignment step) — clamped by
-// the running distance to the closest centre already chosen (closest == NULL: no clamp).  Direct differences, lanes
-// across k, a fixed butterfly: deterministic.  Workgroup = 64 points x up to 16 candidates (their rows sit in LDS); a wave
+// the running distance to the closest centre already chosen (closest == NULL: no clamp).  Direct differences, 16 lanes
+// across k per point, a fixed butterfly: deterministic.  Workgroup = 64 points x up to 16 candidates (their rows sit in LDS); a wave
 // walks 16 of the points, results go through LDS so that the stores are 64 consecutive points of one candidate.
 constexpr int SD_CH = 16;
 __global__ __launch_bounds__(256) void seed_dists_kernel(const float* __restrict__ X, int64_t n, int64_t d,
@@ -397,13 +397,17 @@ __global__ __launch_bounds__(256) void seed_dists_kernel(const float* __restrict
   }
   __syncthreads();
   const int64_t i0 = (int64_t)blockIdx.x * 64;
-  for (int p = 0; p < 16; ++p) {
-    const int64_t i = i0 + w * 16 + p;
+  // a wave walks its 16 points four at a time: 16 lanes per point, k strided by 16 (the four groups read the same
+  // candidate values: LDS broadcast), so the butterfly over a point's lanes is 4 steps for 4 points at once — with one
+  // point per wave the 16 x 6 shuffle steps per point cost as much as the differences themselves
+  const int sub = lane >> 4, sl = lane & 15;
+  for (int p = 0; p < 4; ++p) {
+    const int64_t i = i0 + w * 16 + p * 4 + sub;
     float acc[SD_CH];
 #pragma unroll
     for (int c = 0; c < SD_CH; ++c) acc[c] = 0.0f;
     if (i < n) {
-      for (int64_t k = lane; k < d; k += 64) {
+      for (int64_t k = sl; k < d; k += 16) {
         const float x = X[i * d + k];
 #pragma unroll
         for (int c = 0; c < SD_CH; ++c) {
@@ -414,12 +418,12 @@ __global__ __launch_bounds__(256) void seed_dists_kernel(const float* __restrict
 #pragma unroll
     for (int c = 0; c < SD_CH; ++c) {
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o);
+      for (int o = 8; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o);
     }
-    if (lane == 0) {
+    if (sl == 0) {
 #pragma unroll
       for (int c = 0; c < SD_CH; ++c)
-        if (c < nc) res[c * 64 + w * 16 + p] = acc[c];
+        if (c < nc) res[c * 64 + w * 16 + p * 4 + sub] = acc[c];
     }
   }
   __syncthreads();
