@@ -347,7 +347,7 @@ int mmf_combined_threshold_edges(const float* F, const float* P, int64_t n, int6
  * (k-means++ seeding: the trial candidates of several independent seedings side by side, `group` per seeding, clamped
  * by each seeding's running distance to its closest chosen centre, closest: [ceil(n_cand / group), n]) or, when
  * cand_rows != NULL, the rows of that [n_cand, d] matrix (the centroids of all restarts at once: the assignment step;
- * closest == NULL: no clamp).  Direct differences, fixed summation tree: deterministic.  d <= 32768.
+ * closest == NULL: no clamp).  Direct differences, fixed summation tree: deterministic.
  */
 int mmf_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
                        int64_t group, const float* closest, float* out, int device_id, void* hip_stream);
@@ -359,7 +359,7 @@ int mmf_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand
  * trial candidates with probability proportional to its running closest-centre distance (inverse-CDF sampling, f64
  * sums in a fixed order), forms their clamped distance rows and potentials, and keeps the trial with the smallest
  * potential: three launches per step, all k - 1 steps enqueued by this one call, nothing returns to the host.
- * centre_idx[n_init][k] (device int64): the rows of X chosen as initial centres.  Deterministic.  d <= 32768.
+ * centre_idx[n_init][k] (device int64): the rows of X chosen as initial centres.  Deterministic.
  */
 int mmf_kmeanspp_seed(const float* X, int64_t n, int64_t d, int64_t k, int64_t n_init, int trials, const float* u_first,
                       const float* u_steps, int64_t* centre_idx, int device_id, void* hip_stream);

@@ -367,87 +367,10 @@ int launch_knn_pairs(const int64_t* nbr, int64_t n, int k, const int64_t* labels
 }
 
 // ---- k-means++ seeding ---------------------------------------------------------------------------------------------
-// out[r][i] = min(closest[r / group][i], |x_i - c_r|^2): squared distances of every row to R candidate rows — rows of X picked
-// by index (seeding), or an explicit [R, d] matrix (the centroids of all restarts: the assignment step) — clamped by
-// the running distance to the closest centre already chosen (closest == NULL: no clamp).  Direct differences, 16 lanes
-// across k per point, a fixed butterfly: deterministic.  Workgroup = 64 points x up to 16 candidates (their rows sit in LDS); a wave
-// walks 16 of the points, results go through LDS so that the stores are 64 consecutive points of one candidate.
-constexpr int SD_CH = 16;
-__global__ __launch_bounds__(256) void seed_dists_kernel(const float* __restrict__ X, int64_t n, int64_t d,
-                                                         const int64_t* __restrict__ cand, const float* __restrict__ cand_rows,
-                                                         int64_t n_cand, int64_t group, int ch,
-                                                         const float* __restrict__ closest, float* __restrict__ out,
-                                                         double* __restrict__ partial) {
-  extern __shared__ float sd_smem[];
-  float* cs = sd_smem;                         // [ch][d]
-  float* res = sd_smem + (size_t)ch * d;       // [ch][64]
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t r0 = (int64_t)blockIdx.y * ch;
-  const int nc = (int)((n_cand - r0 < ch) ? (n_cand - r0) : ch);
-  for (int c = 0; c < nc; ++c) {
-    const float* row;
-    if (cand_rows) row = cand_rows + (r0 + c) * d;           // explicit candidate rows (centroids)
-    else {
-      int64_t src = cand[r0 + c];
-      if (src < 0) src = 0;
-      if (src > n - 1) src = n - 1;
-      row = X + src * d;
-    }
-    for (int64_t k = threadIdx.x; k < d; k += 256) cs[(size_t)c * d + k] = row[k];
-  }
-  __syncthreads();
-  const int64_t i0 = (int64_t)blockIdx.x * 64;
-  // a wave walks its 16 points four at a time: 16 lanes per point, k strided by 16 (the four groups read the same
-  // candidate values: LDS broadcast), so the butterfly over a point's lanes is 4 steps for 4 points at once — with one
-  // point per wave the 16 x 6 shuffle steps per point cost as much as the differences themselves
-  const int sub = lane >> 4, sl = lane & 15;
-  for (int p = 0; p < 4; ++p) {
-    const int64_t i = i0 + w * 16 + p * 4 + sub;
-    float acc[SD_CH];
-#pragma unroll
-    for (int c = 0; c < SD_CH; ++c) acc[c] = 0.0f;
-    if (i < n) {
-      for (int64_t k = sl; k < d; k += 16) {
-        const float x = X[i * d + k];
-#pragma unroll
-        for (int c = 0; c < SD_CH; ++c) {
-          if (c < nc) { const float t = x - cs[(size_t)c * d + k]; acc[c] = __builtin_fmaf(t, t, acc[c]); }
-        }
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < SD_CH; ++c) {
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o);
-    }
-    if (sl == 0) {
-#pragma unroll
-      for (int c = 0; c < SD_CH; ++c)
-        if (c < nc) res[c * 64 + w * 16 + p * 4 + sub] = acc[c];
-    }
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < nc * 64; e += 256) {
-    const int c = e >> 6;
-    const int64_t i = i0 + (e & 63);
-    float v = 0.0f;
-    if (i < n) {
-      v = res[e];
-      if (closest) v = fminf(v, closest[((r0 + c) / group) * n + i]);
-      out[(r0 + c) * n + i] = v;
-    }
-    res[e] = v;
-  }
-  if (partial) {                               // potential of every candidate: this workgroup's 64 points, summed in order
-    __syncthreads();
-    if ((int)threadIdx.x < nc) {
-      double sum = 0.0;
-      for (int q = 0; q < 64; ++q) sum += (double)res[threadIdx.x * 64 + q];
-      partial[(r0 + threadIdx.x) * (int64_t)gridDim.x + blockIdx.x] = sum;
-    }
-  }
-}
-
+// The distance rows — out[r][i] = min(closest[r / group][i], |x_i - c_r|^2) with per-tile partial row sums — come from the
+// register-tiled direct-difference kernel of mmf_direct.hip (launch_seed_dists_tiled: 8 x 8 outputs per lane, 0.65 of
+// the vector-ALU roof).  The first version here — candidate rows in LDS, lanes across k, a butterfly per point — reached
+// a tenth of that roof and was 15 of the 25 ms of a fit at N = 16384.
 // One workgroup per seeding: draw `trials` candidates with probability proportional to the running closest-centre
 // distance (inverse-CDF sampling: a thread owns a run of consecutive points, the 1024 run totals are scanned in LDS, a
 // uniform lands in a run by binary search and at a point by walking the run).  f64 sums, fixed order: deterministic.
@@ -531,37 +454,22 @@ __global__ void seed_first_kernel(const float* __restrict__ U0, int64_t n, int64
   cand[i] = j;
 }
 
-int seed_distances_max_dim() { return 32768; }
-static int launch_seed_distances_p(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
-                                   int64_t group, const float* closest, float* out, double* partial, hipStream_t s);
+int seed_distances_max_dim() { return 1 << 20; }
 int launch_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
                           int64_t group, const float* closest, float* out, hipStream_t s) {
-  return launch_seed_distances_p(X, n, d, cand, cand_rows, n_cand, group, closest, out, nullptr, s);
-}
-static int launch_seed_distances_p(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
-                                   int64_t group, const float* closest, float* out, double* partial, hipStream_t s) {
-  if (n <= 0 || n_cand <= 0) return MMF_OK;
-  int ch = (int)(12288 / d);                   // candidate rows per workgroup: up to 48 KiB of LDS
-  if (ch > SD_CH) ch = SD_CH;
-  if (ch < 1) ch = 1;
-  const size_t lds = ((size_t)ch * d + (size_t)ch * 64) * sizeof(float);
-  MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seed_dists_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n_cand + ch - 1) / ch));
-  hipLaunchKernelGGL(seed_dists_kernel, grid, dim3(256), lds, s, X, n, d, cand, cand_rows, n_cand, group, ch, closest, out, partial);
-  MMF_LAUNCH_CHECK();
-  return MMF_OK;
+  return launch_seed_dists_tiled(X, n, d, cand, cand_rows, n_cand, group, closest, out, nullptr, s);
 }
 
 // k-means++ for n_init seedings in lockstep, all k - 1 steps enqueued by this one call (three launches per step).
 // U0 [n_init], U [k - 1][n_init][trials]: uniforms in [0, 1).  scratch: kmeanspp_scratch_bytes.
 size_t kmeanspp_scratch_bytes(int64_t n, int64_t n_init, int trials) {
-  const size_t R = (size_t)n_init * trials, nblk = (size_t)((n + 63) / 64);
+  const size_t R = (size_t)n_init * trials, nblk = (size_t)seed_tiles(n);
   return ((R * n * 4 + 255) & ~size_t(255)) + (((size_t)n_init * n * 4 + 255) & ~size_t(255)) + ((R * nblk * 8 + 255) & ~size_t(255)) +
          ((R * 8 + 255) & ~size_t(255)) + 256;
 }
 int launch_kmeanspp(const float* X, int64_t n, int64_t d, int64_t k, int64_t n_init, int trials, const float* U0, const float* U,
                     int64_t* cidx, void* scratch, hipStream_t s) {
-  const size_t R = (size_t)n_init * trials, nblk = (size_t)((n + 63) / 64);
+  const size_t R = (size_t)n_init * trials, nblk = (size_t)seed_tiles(n);
   char* p = static_cast<char*>(scratch);
   float* dc = reinterpret_cast<float*>(p); p += (R * n * 4 + 255) & ~size_t(255);
   float* closest = reinterpret_cast<float*>(p); p += ((size_t)n_init * n * 4 + 255) & ~size_t(255);
@@ -569,11 +477,11 @@ int launch_kmeanspp(const float* X, int64_t n, int64_t d, int64_t k, int64_t n_i
   int64_t* cand = reinterpret_cast<int64_t*>(p);
   hipLaunchKernelGGL(seed_first_kernel, dim3((unsigned)((n_init + 63) / 64)), dim3(64), 0, s, U0, n, n_init, k, cidx, cand);
   MMF_LAUNCH_CHECK();
-  MMF_TRY(launch_seed_distances_p(X, n, d, cand, nullptr, n_init, 1, nullptr, closest, nullptr, s));
+  MMF_TRY(launch_seed_dists_tiled(X, n, d, cand, nullptr, n_init, 1, nullptr, closest, nullptr, s));
   for (int64_t step = 1; step < k; ++step) {
     hipLaunchKernelGGL(seed_draw_kernel, dim3((unsigned)n_init), dim3(1024), 0, s, closest, n, U + (step - 1) * n_init * trials, trials, cand);
     MMF_LAUNCH_CHECK();
-    MMF_TRY(launch_seed_distances_p(X, n, d, cand, nullptr, (int64_t)R, trials, closest, dc, partial, s));
+    MMF_TRY(launch_seed_dists_tiled(X, n, d, cand, nullptr, (int64_t)R, trials, closest, dc, partial, s));
     hipLaunchKernelGGL(seed_choose_kernel, dim3((unsigned)n_init), dim3(256), 0, s, dc, partial, (int64_t)nblk, n, trials, cand, closest,
                        cidx, k, step);
     MMF_LAUNCH_CHECK();
