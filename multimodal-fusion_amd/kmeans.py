@@ -56,9 +56,9 @@ def kmeans_fit_predict(X: torch.Tensor, n_clusters: int, *, n_init: int = 10, ma
     tol_abs = float(tol) * float(Xc.var(dim=0, unbiased=False).mean())
     gen = torch.Generator(device=X.device).manual_seed(int(seed))
     C = _kmeanspp(Xc, n_clusters, n_init, gen)                                # [n_init, k, D]
-    # lockstep pays while the [n_init * k, N] distance rows are small (measured: N = 16384, k = 100: 43 -> 36 ms per fit,
-    # 10 groups of 100 rows: 8 -> 2 ms; N = 65536: 112 -> 150 ms, so large problems go restart by restart)
-    if n_init * n_clusters <= 16384 and n_init * n_clusters * n <= (1 << 24):
+    # lockstep while the [n_init * k, N] distance rows stay within 512 MiB (measured with the tiled distance kernel:
+    # N = 65536, k = 100: 61 -> 40 ms per fit; 10 groups of 100 rows: 8 -> 2 ms); beyond that restart by restart
+    if n_init * n_clusters <= 16384 and n_init * n_clusters * n <= (1 << 27):
         labels, C, inertia = _lloyd_lockstep(Xc, C, max_iter, tol_abs)
     else:
         labels, C, inertia = _lloyd_one_by_one(Xc, C, max_iter, tol_abs)
