@@ -255,15 +255,108 @@ int launch_rbf_direct(const void* X, int64_t n, const void* Y, int64_t m, int64_
   return MMF_OK;
 }
 
+// The seeding epilogue on 64 x 64 tiles, 4 x 4 outputs per lane: for launches too small to fill the chip with 128 x 128
+// tiles (a k-means++ step at N = 16384 is 60 candidate rows = 128 such tiles, each of them 107 us of work wherever it runs).
+constexpr int S_B = 64, S_LD = 68;
+template <bool VEC4>
+__global__ __launch_bounds__(256) void seed_tile64_kernel(const float* __restrict__ A, int64_t n, const float* __restrict__ Y, int64_t m,
+                                                          int64_t d, float* __restrict__ out, SeedArgs sa) {
+  __shared__ __attribute__((aligned(16))) float As[2][D_KC][S_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][D_KC][S_LD];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int64_t i0 = (int64_t)blockIdx.y * S_B, j0 = (int64_t)blockIdx.x * S_B;
+  const int srow = tid >> 2, sk = (tid & 3) * 4;
+  int64_t xr = i0 + srow, yr = j0 + srow;
+  if (xr > n - 1) xr = n - 1;
+  if (yr > m - 1) yr = m - 1;
+  if (sa.row_idx) xr = sa.row_idx[xr];
+  f32x4 ra, rb;
+  auto gload = [&](int64_t k0) {
+    ra = dload4<VEC4>(A, xr, k0 + sk, d, MMF_F32);
+    rb = dload4<VEC4>(Y, yr, k0 + sk, d, MMF_F32);
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { As[buf][sk + e][srow] = ra[e]; Bs[buf][sk + e][srow] = rb[e]; }
+  };
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+  const int nk = (int)((d + D_KC - 1) / D_KC);
+  gload(0);
+  swrite(0);
+  __syncthreads();
+  for (int s = 0; s < nk; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nk) gload((int64_t)(s + 1) * D_KC);
+#pragma unroll 4
+    for (int k = 0; k < D_KC; ++k) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&As[buf][k][ty * 4]);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[buf][k][tx * 4]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float t = a[i] - b[j];
+          acc[i][j] = __builtin_fmaf(t, t, acc[i][j]);
+        }
+    }
+    if (s + 1 < nk) swrite(buf ^ 1);
+    __syncthreads();
+  }
+  const bool vst = ((m & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t row = i0 + ty * 4 + i;
+    float rs = 0.0f;
+    if (row < n) {
+      const float* cl = sa.closest ? sa.closest + (row / sa.group) * m : nullptr;
+      const int64_t col = j0 + tx * 4;
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = acc[i][j];
+        if (cl && col + j < m) v[j] = fminf(v[j], cl[col + j]);
+        if (col + j < m) rs += v[j];
+      }
+      if (vst && col + 3 < m) *reinterpret_cast<f32x4*>(out + row * m + col) = v;
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (col + j < m) out[row * m + col + j] = v[j];
+      }
+    }
+    if (sa.partial) {
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) rs += __shfl_xor(rs, o);
+      if (tx == 0 && row < n) sa.partial[row * (int64_t)gridDim.x + blockIdx.x] = (double)rs;
+    }
+  }
+}
+
 // out[r][i] = min(closest[r / group][i], |x_i - c_r|^2) for n_cand candidate rows c_r (rows of X by index, or explicit rows)
-// against all n rows of X; partial (optional): [n_cand][seed_tiles(n)] sums of the clamped rows per 128-column tile.
-int64_t seed_tiles(int64_t n) { return (n + D_BN - 1) / D_BN; }
+// against all n rows of X; partial (optional): [n_cand][seed_tiles(n, n_cand)] sums of the clamped rows per column tile.
+static int seed_tile_width(int64_t n, int64_t n_cand) {
+  const int64_t big = ((n + D_BN - 1) / D_BN) * ((n_cand + D_BM - 1) / D_BM);
+  return big < 512 ? S_B : D_BN;                // few 128 x 128 tiles: 64 x 64 ones fill the chip and finish sooner
+}
+int64_t seed_tiles(int64_t n, int64_t n_cand) { const int w = seed_tile_width(n, n_cand); return (n + w - 1) / w; }
 int launch_seed_dists_tiled(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
                             int64_t group, const float* closest, float* out, double* partial, hipStream_t s) {
   if (n <= 0 || n_cand <= 0) return MMF_OK;
   const float* A = cand_rows ? cand_rows : X;
-  const dim3 grid((unsigned)((n + D_BN - 1) / D_BN), (unsigned)((n_cand + D_BM - 1) / D_BM));
   SeedArgs sa{cand_rows ? nullptr : cand, closest, group, partial};
+  if (seed_tile_width(n, n_cand) == S_B) {
+    const dim3 g64((unsigned)((n + S_B - 1) / S_B), (unsigned)((n_cand + S_B - 1) / S_B));
+    if (direct_vec4(A, X, d, MMF_F32)) hipLaunchKernelGGL(seed_tile64_kernel<true>, g64, dim3(256), 0, s, A, n_cand, X, n, d, out, sa);
+    else hipLaunchKernelGGL(seed_tile64_kernel<false>, g64, dim3(256), 0, s, A, n_cand, X, n, d, out, sa);
+    MMF_LAUNCH_CHECK();
+    return MMF_OK;
+  }
+  const dim3 grid((unsigned)((n + D_BN - 1) / D_BN), (unsigned)((n_cand + D_BM - 1) / D_BM));
   if (direct_vec4(A, X, d, MMF_F32))
     hipLaunchKernelGGL((rbf_direct_tiled_kernel<true, EPI_SEED>), grid, dim3(256), 0, s, A, n_cand, X, n, d, MMF_F32, 0.0f, out, nullptr, nullptr, sa);
   else

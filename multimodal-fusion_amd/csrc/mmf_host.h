@@ -219,7 +219,7 @@ size_t clique_scratch_bytes(int64_t n, int64_t S);
 int launch_clique_pairs(const int64_t* order, const int64_t* offsets, int64_t n, int64_t S, int64_t* lo, int64_t* hi,
                         int64_t capacity, int64_t* out_count, void* scratch, hipStream_t s);
 int seed_distances_max_dim();
-int64_t seed_tiles(int64_t n);          // mmf_direct.hip: 128-column tiles of the seeding-distance kernel
+int64_t seed_tiles(int64_t n, int64_t n_cand);   // mmf_direct.hip: column tiles of the seeding-distance launch for this shape
 int launch_seed_dists_tiled(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
                             int64_t group, const float* closest, float* out, double* partial, hipStream_t s);
 int launch_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,

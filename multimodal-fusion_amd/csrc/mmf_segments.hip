@@ -463,13 +463,13 @@ int launch_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* c
 // k-means++ for n_init seedings in lockstep, all k - 1 steps enqueued by this one call (three launches per step).
 // U0 [n_init], U [k - 1][n_init][trials]: uniforms in [0, 1).  scratch: kmeanspp_scratch_bytes.
 size_t kmeanspp_scratch_bytes(int64_t n, int64_t n_init, int trials) {
-  const size_t R = (size_t)n_init * trials, nblk = (size_t)seed_tiles(n);
+  const size_t R = (size_t)n_init * trials, nblk = (size_t)seed_tiles(n, (int64_t)n_init * trials);
   return ((R * n * 4 + 255) & ~size_t(255)) + (((size_t)n_init * n * 4 + 255) & ~size_t(255)) + ((R * nblk * 8 + 255) & ~size_t(255)) +
          ((R * 8 + 255) & ~size_t(255)) + 256;
 }
 int launch_kmeanspp(const float* X, int64_t n, int64_t d, int64_t k, int64_t n_init, int trials, const float* U0, const float* U,
                     int64_t* cidx, void* scratch, hipStream_t s) {
-  const size_t R = (size_t)n_init * trials, nblk = (size_t)seed_tiles(n);
+  const size_t R = (size_t)n_init * trials, nblk = (size_t)seed_tiles(n, (int64_t)n_init * trials);
   char* p = static_cast<char*>(scratch);
   float* dc = reinterpret_cast<float*>(p); p += (R * n * 4 + 255) & ~size_t(255);
   float* closest = reinterpret_cast<float*>(p); p += ((size_t)n_init * n * 4 + 255) & ~size_t(255);
