@@ -341,7 +341,9 @@ __global__ __launch_bounds__(256) void seed_tile64_kernel(const float* __restric
 // against all n rows of X; partial (optional): [n_cand][seed_tiles(n, n_cand)] sums of the clamped rows per column tile.
 static int seed_tile_width(int64_t n, int64_t n_cand) {
   const int64_t big = ((n + D_BN - 1) / D_BN) * ((n_cand + D_BM - 1) / D_BM);
-  return big < 512 ? S_B : D_BN;                // few 128 x 128 tiles: 64 x 64 ones fill the chip and finish sooner
+  // few 128 x 128 tiles: 64 x 64 ones fill the chip and finish sooner; up to 64 candidate rows: a 128-row tile would
+  // spend half its work on padding
+  return (big < 512 || n_cand <= S_B) ? S_B : D_BN;
 }
 int64_t seed_tiles(int64_t n, int64_t n_cand) { const int w = seed_tile_width(n, n_cand); return (n + w - 1) / w; }
 int launch_seed_dists_tiled(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
