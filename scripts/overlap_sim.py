@@ -31,21 +31,28 @@ for P in ((8,) if OCC_WGS else (2, 4, 8)):
     mode = {"record": True}
     calls = {"i": 0}
     # pass 1 (record): run every rank's local phase to learn what the gathers return
-    def gather(out, inp, group, async_op=False):
+    def gather(out, inp, group):
         key = calls["i"]; calls["i"] += 1
         if mode["record"]:
             store.setdefault(key, {})[mode["rank"]] = inp.clone()
             out.view(P, -1)[mode["rank"]] = inp.reshape(-1)
         else:
             out.copy_(store[key].view(out.shape))
-        return FakeWork() if async_op else None
+    def gather_event(out, inp, group, side_stream):
+        # the stand-in for an asynchronous all-gather: a device copy on the side stream, event recorded behind it
+        ev = torch.cuda.Event()
+        side_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side_stream):
+            gather(out, inp, group)
+            ev.record(side_stream)
+        return ev
     def armax(t, group):
         key = "m%d" % calls["i"]; calls["i"] += 1
         if mode["record"]:
             store[key] = torch.maximum(store[key], t.clone()) if key in store else t.clone()
         else:
             t.copy_(store[key])
-    dmod._gather_into, dmod._allreduce_max = gather, armax
+    dmod._gather_into, dmod._gather_event, dmod._allreduce_max = gather, gather_event, armax
     import torch.distributed as dist
     for r in range(P):
         mode["rank"] = r; calls["i"] = 0
