@@ -13,5 +13,5 @@ for it in range(2):
     torch.cuda.synchronize(); t1 = time.perf_counter()
     ei, ew = ops.combined_threshold_edges(F, P, float(med), 1.0, 1.0)
     torch.cuda.synchronize(); t2 = time.perf_counter()
-print("N=%d d=%d: median %.1f ms (4 sweeps, %.0f TFLOP/s), edges %.1f ms (2 sweeps, %d edges = %.1f GB written); K itself would be %.1f GB"
-      % (N, d, (t1 - t0) * 1e3, 4 * 2.0 * N * N * d / (t1 - t0) / 1e12, (t2 - t1) * 1e3, ei.shape[1], ei.shape[1] * 20 / 1e9, N * N * 4 / 1e9))
+print("N=%d d=%d: median %.1f ms (one sweep when the sampled bracket holds: %.0f TFLOP/s), edges %.1f ms (2 sweeps, %d edges = %.1f GB written); K itself would be %.1f GB"
+      % (N, d, (t1 - t0) * 1e3, 2.0 * N * N * d / (t1 - t0) / 1e12, (t2 - t1) * 1e3, ei.shape[1], ei.shape[1] * 20 / 1e9, N * N * 4 / 1e9))
