@@ -438,8 +438,9 @@ __global__ __launch_bounds__(256) void seed_choose_kernel(const float* __restric
   const int bs = best_s;
   const float* src = dc + (i * trials + bs) * n;
   float* dst = closest + i * n;
-  for (int64_t j = t; j < n; j += 256) dst[j] = src[j];
-  if (t == 0) cidx[i * k + step] = cand[i * trials + bs];
+  // the row copy is shared by the gridDim.y workgroups of this seeding (each finds the same best trial for itself)
+  for (int64_t j = (int64_t)blockIdx.y * 256 + t; j < n; j += (int64_t)gridDim.y * 256) dst[j] = src[j];
+  if (t == 0 && blockIdx.y == 0) cidx[i * k + step] = cand[i * trials + bs];
 }
 
 // first centre of every seeding: a uniform index
@@ -478,11 +479,14 @@ int launch_kmeanspp(const float* X, int64_t n, int64_t d, int64_t k, int64_t n_i
   hipLaunchKernelGGL(seed_first_kernel, dim3((unsigned)((n_init + 63) / 64)), dim3(64), 0, s, U0, n, n_init, k, cidx, cand);
   MMF_LAUNCH_CHECK();
   MMF_TRY(launch_seed_dists_tiled(X, n, d, cand, nullptr, n_init, 1, nullptr, closest, nullptr, s));
+  unsigned choose_split = (unsigned)((n + 2047) / 2048);      // workgroups per seeding that share the row copy of the choice
+  if (choose_split > 32) choose_split = 32;
+  if (choose_split < 1) choose_split = 1;
   for (int64_t step = 1; step < k; ++step) {
     hipLaunchKernelGGL(seed_draw_kernel, dim3((unsigned)n_init), dim3(1024), 0, s, closest, n, U + (step - 1) * n_init * trials, trials, cand);
     MMF_LAUNCH_CHECK();
     MMF_TRY(launch_seed_dists_tiled(X, n, d, cand, nullptr, (int64_t)R, trials, closest, dc, partial, s));
-    hipLaunchKernelGGL(seed_choose_kernel, dim3((unsigned)n_init), dim3(256), 0, s, dc, partial, (int64_t)nblk, n, trials, cand, closest,
+    hipLaunchKernelGGL(seed_choose_kernel, dim3((unsigned)n_init, choose_split), dim3(256), 0, s, dc, partial, (int64_t)nblk, n, trials, cand, closest,
                        cidx, k, step);
     MMF_LAUNCH_CHECK();
   }
