@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 1
+#define MMF_ABI_VERSION 2
 
 /* return codes */
 #define MMF_OK             0
@@ -363,6 +363,31 @@ int mmf_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand
  */
 int mmf_kmeanspp_seed(const float* X, int64_t n, int64_t d, int64_t k, int64_t n_init, int trials, const float* u_first,
                       const float* u_steps, int64_t* centre_idx, int device_id, void* hip_stream);
+
+/*
+ * The reference's clustering call, KMeans(n_clusters, random_state=seed, n_init=n_init).fit_predict(X)
+ * (build_hypergraph/preprocess_hypergraph.py:150-151, 299-300, 391-392), on the device and DECISION FOR DECISION:
+ * scikit-learn's k-means++ seeding, Lloyd iterations, convergence tests and choice of the best restart
+ * (sklearn/cluster/_kmeans.py 1.7.2: KMeans.fit, _kmeans_plusplus, _kmeans_single_lloyd), with every inner product and
+ * sum taken in float64 on the matrix cores and rounded to float32 exactly where scikit-learn stores a float32.
+ * scikit-learn's own float32 sums go through BLAS in a machine-dependent order; wherever one of its decisions is not
+ * taken by that rounding noise, this entry takes the same one, so the labels are scikit-learn's
+ * (oracle/kmeans_restate.py is the CPU restatement of this contract; tests/golden g5 / g8 hold scikit-learn's labels).
+ *
+ * The caller supplies scikit-learn's random stream, which is data independent: with rs = numpy.random.RandomState(seed),
+ * per restart one rs.random_sample() (the first centre: RandomState.choice(n, p=uniform), passed here as the resulting
+ * row index first_centres[n_init]) followed by n_clusters - 1 draws of rs.uniform(size=trials), trials = 2 + int(log(k)):
+ * uniforms[n_init][n_clusters - 1][trials].  BOTH ARE HOST ARRAYS.  All restarts advance in lockstep.
+ *   X [n, d] f32 device (not modified); labels [n] int64 device; centres [n_clusters, d] f32 device or NULL;
+ *   seeds [n_init, n_clusters] int64 device or NULL (the rows chosen as initial centres);
+ *   info (host, 7 + 2 n_init doubles, or NULL): best restart, its inertia, its iterations, the absolute tolerance,
+ *   draws / trial choices within 4 float32 ulps of going the other way, lockstep iterations, then (inertia, iterations)
+ *   per restart.
+ * Host-synchronous (one small status read per Lloyd iteration).  n_init * n_clusters <= 16384, trials <= 64.
+ */
+int mmf_kmeans_fit(const float* X, int64_t n, int64_t d, int64_t n_clusters, int64_t n_init, int trials,
+                   const int64_t* first_centres, const double* uniforms, int max_iter, double tol, int64_t* labels,
+                   float* centres, int64_t* seeds, double* info, int device_id, void* hip_stream);
 
 int mmf_segment_sort(const int64_t* labels, int64_t n, int64_t n_segments, int64_t* counts, int64_t* offsets,
                      int64_t* order, int device_id, void* hip_stream);

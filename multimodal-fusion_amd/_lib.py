@@ -13,6 +13,7 @@ DOT, COSINE, NEG_SQ_L2, RBF, RBF_DIRECT = 0, 1, 2, 3, 4
 METRICS = {"dot": DOT, "cosine": COSINE, "neg_sq_l2": NEG_SQ_L2, "rbf": RBF, "rbf_direct": RBF_DIRECT}
 F32, BF16, F16 = 0, 1, 2
 PRECISIONS = {"auto": 0, "exact": 1, "fast": 2, "fast_bf16": 3}
+ABI_VERSION = 2          # MMF_ABI_VERSION of the include/mmf_hg.h this binding was written against
 
 
 class SimtopkOpts(ctypes.Structure):
@@ -46,7 +47,7 @@ _lib = None
 EXPORTS = ["mmf_version", "mmf_last_error", "mmf_simtopk", "mmf_simtopk_ex", "mmf_row_scalars", "mmf_prep_rows",
            "mmf_simtopk_prepared", "mmf_simtopk_panels", "mmf_padded_dim", "mmf_fast_scan_supported", "mmf_topk_merge", "mmf_edge_cosine",
            "mmf_sim_dense", "mmf_sim_dense_stats", "mmf_sim_dense_combined", "mmf_offdiag_lower_median", "mmf_threshold_edges", "mmf_lower_median", "mmf_array_stats",
-           "mmf_segment_sort", "mmf_segment_mean", "mmf_segment_offdiag_mean", "mmf_clique_pairs", "mmf_knn_pairs", "mmf_seed_distances", "mmf_kmeanspp_seed", "mmf_combined_offdiag_median", "mmf_combined_threshold_edges",
+           "mmf_segment_sort", "mmf_segment_mean", "mmf_segment_offdiag_mean", "mmf_clique_pairs", "mmf_knn_pairs", "mmf_seed_distances", "mmf_kmeanspp_seed", "mmf_kmeans_fit", "mmf_combined_offdiag_median", "mmf_combined_threshold_edges",
            "mmf_release_workspaces"]
 
 
@@ -88,6 +89,7 @@ def lib() -> ctypes.CDLL:
     L.mmf_knn_pairs.argtypes = [vp, i64, ci, vp, vp, vp, vp, ci, vp]
     L.mmf_seed_distances.argtypes = [vp, i64, i64, vp, vp, i64, i64, vp, vp, ci, vp]
     L.mmf_kmeanspp_seed.argtypes = [vp, i64, i64, i64, i64, ci, vp, vp, vp, ci, vp]
+    L.mmf_kmeans_fit.argtypes = [vp, i64, i64, i64, i64, ci, vp, vp, ci, ctypes.c_double, vp, vp, vp, vp, ci, vp]
     L.mmf_lower_median.argtypes = [vp, i64, vp, ci, vp]
     L.mmf_array_stats.argtypes = [vp, i64, vp, ci, vp]
     L.mmf_threshold_edges.argtypes = [vp, i64, f32, vp, vp, i64, vp, ci, vp]
@@ -99,8 +101,9 @@ def lib() -> ctypes.CDLL:
             fn.restype = ci
     L.mmf_padded_dim.restype = i64
     L.mmf_last_error.restype = ctypes.c_char_p
-    if L.mmf_version() != 1:
-        raise RuntimeError(f"libmmf_hg.so ABI version {L.mmf_version()} != 1")
+    if L.mmf_version() != ABI_VERSION:
+        raise RuntimeError(f"{SO_PATH}: ABI version {L.mmf_version()}, this package binds version {ABI_VERSION} "
+                           "(include/mmf_hg.h MMF_ABI_VERSION): rebuild the library")
     _lib = L
     return L
 

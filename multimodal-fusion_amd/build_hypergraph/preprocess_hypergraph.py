@@ -16,11 +16,12 @@ shapes and error behaviour; the arithmetic runs in the gfx950 kernels behind inc
     rebuild_hypergraph_from_similarity :758-916  incl. the edge-weight median filter (:885-897) on mmf_lower_median
     batch_rebuild_hypergraph         :919-990
 
-KMeans: `sklearn.cluster.KMeans(n_clusters, random_state=42, n_init=10)` in the reference (:150, :299, :391).  Its
-labels depend on scikit-learn's seeding stream, which no other implementation reproduces, so the default backend
-here is the device KMeans of multimodal-fusion_amd/kmeans.py (same objective; deterministic);
-`set_kmeans_backend("sklearn")` (or MMF_KMEANS_BACKEND=sklearn) runs the reference's own call on the host and
-reproduces its labels — and with them its edges — exactly (tests/golden g5, g8).
+KMeans: `sklearn.cluster.KMeans(n_clusters, random_state=42, n_init=10)` in the reference (:150, :299, :391).  The default
+backend is the device KMeans of multimodal-fusion_amd/kmeans.py (csrc/mmf_kmeans.hip), which takes scikit-learn's
+decisions one by one — its random stream is drawn with numpy's RandomState(42) in scikit-learn's order, every sum is formed
+in float64 — and returns scikit-learn's labels (tests/golden g5, g8, g9; scikit-learn's own float32 BLAS sums make its
+result machine dependent where a decision hangs on rounding noise: DESIGN.md §4.5).  `set_kmeans_backend("sklearn")`,
+MMF_KMEANS_BACKEND=sklearn or --kmeans_backend sklearn runs the reference's own call on the host instead.
 
 Documented divergences (SURVEY.md Appendix A): self is dropped from the k-NN by identity instead of "column 0" (A5);
 edges come out lexicographically sorted instead of in Python set order (A6); stats hold Python scalars (A3); an
@@ -42,8 +43,8 @@ from ._common import compute_device, result_device_like_preprocess, to_gpu
 from .similarity_kernel import compute_combined_similarity
 
 KMEANS_BACKEND = os.environ.get("MMF_KMEANS_BACKEND", "device")
-# "device" : multimodal-fusion_amd/kmeans.py (k-means++ + Lloyd on the hot-path kernels)
-# "sklearn": the reference's own call on the host (labels identical to the reference)
+# "device" : multimodal-fusion_amd/kmeans.py (scikit-learn's fit, decision for decision, on the GPU; labels identical)
+# "sklearn": the reference's own call on the host
 
 
 def set_kmeans_backend(name: str) -> None:
@@ -54,7 +55,7 @@ def set_kmeans_backend(name: str) -> None:
 
 
 def _kmeans_labels(x: torch.Tensor, n_clusters: int) -> torch.Tensor:
-    """int64 labels on x's (ROCm) device."""
+    """int64 labels on x's (ROCm) device: KMeans(n_clusters, random_state=42, n_init=10).fit_predict(x)."""
     if KMEANS_BACKEND == "device":
         from ..kmeans import kmeans_fit_predict
         return kmeans_fit_predict(x, n_clusters, n_init=10, seed=42)[0]
@@ -148,7 +149,7 @@ def group_by_similarity(similarity_matrix: torch.Tensor, num_groups: int, method
     labels = _kmeans_labels(to_gpu(similarity_matrix, dev), num_groups)
     sizes = torch.bincount(labels, minlength=num_groups).cpu().tolist()
     stats = {"method": "kmeans", "num_groups": num_groups, "group_sizes": [int(v) for v in sizes]}
-    return labels.cpu().numpy(), stats
+    return labels.cpu().numpy().astype(np.int32), stats      # scikit-learn's label dtype: what the reference writes to group_labels
 
 
 def build_hypergraph_knn_kmeans(wsi_features: torch.Tensor, tma_features: torch.Tensor, group_labels: np.ndarray,
@@ -398,7 +399,11 @@ def _main(argv=None):
     ap.add_argument("--lambda_g", type=float, default=1.0)
     ap.add_argument("--output_stats", type=str, default=None)
     ap.add_argument("--device", type=str, default="auto")
+    ap.add_argument("--kmeans_backend", type=str, default=None, choices=["device", "sklearn"],
+                    help="not a reference flag: where KMeans runs (default: MMF_KMEANS_BACKEND or 'device'; same labels)")
     a = ap.parse_args(argv)
+    if a.kmeans_backend:
+        set_kmeans_backend(a.kmeans_backend)
     device = torch.device("cuda" if torch.cuda.is_available() else "cpu") if a.device == "auto" else torch.device(a.device)
     process_dataset(a.csv_path, a.data_root_dir, a.num_wsi_super_patches, a.num_groups, a.hypergraph_k, a.num_hyperedges,
                     a.lambda_h, a.lambda_g, a.output_stats, device)

@@ -5,7 +5,7 @@ it): rebuild every file's hypergraph from its stored similarity matrices with ot
 """
 import argparse
 
-from .preprocess_hypergraph import batch_rebuild_hypergraph
+from .preprocess_hypergraph import batch_rebuild_hypergraph, set_kmeans_backend
 
 
 def main(argv=None):
@@ -18,7 +18,11 @@ def main(argv=None):
     ap.add_argument("--num_hyperedges", type=int, default=10)
     ap.add_argument("--threshold_median_ratio", type=float, default=None, help="edge-weight median filter (None: off)")
     ap.add_argument("--output_stats", type=str, default=None)
+    ap.add_argument("--kmeans_backend", type=str, default=None, choices=["device", "sklearn"],
+                    help="not a reference flag: where KMeans runs (default: MMF_KMEANS_BACKEND or 'device'; same labels)")
     a = ap.parse_args(argv)
+    if a.kmeans_backend:
+        set_kmeans_backend(a.kmeans_backend)
     return batch_rebuild_hypergraph(a.csv_path, a.data_root_dir, num_wsi_super_patches=a.num_wsi_super_patches,
                                     num_groups=a.num_groups, hypergraph_k=a.hypergraph_k, num_hyperedges=a.num_hyperedges,
                                     threshold_median_ratio=a.threshold_median_ratio, output_stats_path=a.output_stats)

@@ -998,6 +998,33 @@ int mmf_kmeanspp_seed(const float* X, int64_t n, int64_t d, int64_t k, int64_t n
   return launch_kmeanspp(X, n, d, k, n_init, trials, u_first, u_steps, centre_idx, ws.take<char>(need), s);
 }
 
+int mmf_kmeans_fit(const float* X, int64_t n, int64_t d, int64_t n_clusters, int64_t n_init, int trials, const int64_t* first_centres,
+                   const double* uniforms, int max_iter, double tol, int64_t* labels, float* centres, int64_t* seeds, double* info,
+                   int device_id, void* hip_stream) {
+  if (device_id < 0) { set_error("kmeans_fit: no CPU path"); return MMF_E_UNSUPPORTED; }
+  if (n < 1 || d < 1 || n_clusters < 1 || n_clusters > n || n_init < 1 || trials < 1 || trials > 64 || max_iter < 1 || !(tol >= 0.0)) {
+    set_error("kmeans_fit: need 1 <= n_clusters <= n, n_init >= 1, 1 <= trials <= 64, max_iter >= 1, tol >= 0 (n = %lld, n_clusters = %lld, "
+              "n_init = %lld, trials = %d, max_iter = %d)", (long long)n, (long long)n_clusters, (long long)n_init, trials, max_iter);
+    return MMF_E_INVALID;
+  }
+  if (n_init * n_clusters > segment_max_segments()) {
+    set_error("kmeans_fit: n_init * n_clusters = %lld above the supported %d", (long long)(n_init * n_clusters), segment_max_segments());
+    return MMF_E_UNSUPPORTED;
+  }
+  if (n_init * n >= ((int64_t)1 << 31)) { set_error("kmeans_fit: n_init * n must be < 2^31"); return MMF_E_UNSUPPORTED; }
+  if (!X || !first_centres || (n_clusters > 1 && !uniforms) || !labels) { set_error("kmeans_fit: NULL pointer"); return MMF_E_INVALID; }
+  for (int64_t i = 0; i < n_init; ++i)
+    if (first_centres[i] < 0 || first_centres[i] >= n) { set_error("kmeans_fit: first_centres[%lld] outside [0, n)", (long long)i); return MMF_E_INVALID; }
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  const size_t need = kmeans_scratch_bytes(n, d, n_clusters, n_init, trials);
+  Workspace ws;
+  MMF_TRY(get_workspace(device_id, s, ws_bytes(need, 1), &ws));
+  return launch_kmeans_fit(X, n, d, n_clusters, n_init, trials, first_centres, uniforms, max_iter, tol, labels, centres, seeds, info,
+                           ws.take<char>(need), s);
+}
+
 int mmf_lower_median(const float* v, int64_t count, float* out_median, int device_id, void* hip_stream) {
   if (device_id < 0) { set_error("lower_median: no CPU path"); return MMF_E_UNSUPPORTED; }
   if (count < 1) { set_error("lower_median: need count >= 1 (got %lld)", (long long)count); return MMF_E_INVALID; }

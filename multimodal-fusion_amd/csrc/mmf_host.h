@@ -7,6 +7,7 @@
 #include <stdio.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/mmf_hg.h"
 
@@ -227,6 +228,11 @@ int launch_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* c
 size_t kmeanspp_scratch_bytes(int64_t n, int64_t n_init, int trials);
 int launch_kmeanspp(const float* X, int64_t n, int64_t d, int64_t k, int64_t n_init, int trials, const float* U0, const float* U,
                     int64_t* cidx, void* scratch, hipStream_t s);
+// mmf_kmeans.hip: scikit-learn's KMeans fit, decision for decision, all restarts in lockstep (host-synchronous)
+size_t kmeans_scratch_bytes(int64_t n, int64_t d, int64_t k, int64_t n_init, int trials);
+int launch_kmeans_fit(const float* X, int64_t n, int64_t d, int64_t k, int64_t n_init, int trials, const int64_t* first_h,
+                      const double* u_h, int max_iter, double tol, int64_t* out_labels, float* out_centres, int64_t* out_seeds,
+                      double* info_h, void* scratch, hipStream_t s);
 int launch_knn_pairs(const int64_t* nbr, int64_t n, int k, const int64_t* labels, int64_t* lo, int64_t* hi, int64_t* out_count,
                      hipStream_t s);
 

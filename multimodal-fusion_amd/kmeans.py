@@ -1,127 +1,65 @@
-"""Device KMeans: k-means++ seeding + Lloyd iterations on the GPU.
+"""Device KMeans: the reference's clustering call, reproduced on the GPU.
 
-The reference clusters with ``sklearn.cluster.KMeans(n_clusters, random_state=42, n_init=10)`` on
-the host (build_hypergraph/preprocess_hypergraph.py:150-151, 299-300, 391-392).  Here the two
-distance computations that dominate it run on the hot-path kernels of libmmf_hg.so:
+The reference clusters with ``sklearn.cluster.KMeans(n_clusters, random_state=42, n_init=10).fit_predict(x)`` on the host
+(build_hypergraph/preprocess_hypergraph.py:150-151, 299-300, 391-392); the labels decide the super-patches, the groups
+and the clique hyperedges.  ``mmf_kmeans_fit`` (csrc/mmf_kmeans.hip) takes the same decisions scikit-learn takes, in the
+same order: k-means++ seeding with ``2 + int(log k)`` local trials, Lloyd iterations with scikit-learn's two convergence
+tests, the best of ``n_init`` restarts by inertia — every inner product and sum in float64 on the matrix cores, rounded to
+float32 exactly where scikit-learn stores a float32.  What makes the labels scikit-learn's own is its random stream, and
+that stream does not depend on the data: this module draws it on the host with ``numpy.random.RandomState(seed)`` in
+scikit-learn's order of consumption (sklearn/cluster/_kmeans.py 1.7.2, ``_kmeans_plusplus``: per restart one
+``random_sample()`` for the first centre, then one ``uniform(size=trials)`` per seeding step) and hands it to the
+library, which runs all restarts in lockstep.
 
-* assignment  = fused similarity + top-1 (``mmf_simtopk``, squared L2, k = 1) of every point against
-  the centroids — labels and distances come out of one scan, the N x k matrix is never stored;
-* k-means++    = all n_init seedings in lockstep inside the library (``mmf_kmeanspp_seed``: draw, distance rows,
-  choice — three launches per seeding step, no host round trip).
-
-Centroid updates are segmented means in a fixed summation order (``mmf_segment_sort`` + ``mmf_segment_mean``), so the
-whole fit is deterministic: same data and seed, same labels, run after run.  Bit-parity with scikit-learn is not
-achievable (its seeding consumes a Mersenne-Twister stream); parity is on the objective: same
-partition on separable data, inertia within a few per cent otherwise (tests/test_gpu_kmeans.py).
+scikit-learn's own float32 sums go through BLAS in an order that depends on the CPU and the thread count, so its labels
+are themselves reproducible only up to the decisions that rounding noise takes; ``info['ambiguous_draws']`` /
+``['ambiguous_trials']`` count the seeding decisions that came within 4 float32 ulps of going the other way.
 """
 from __future__ import annotations
 
 import math
 from typing import Tuple
 
+import numpy as np
 import torch
 
 from . import ops
 
 
-def _assign(X: torch.Tensor, C: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    idx, val = ops.simtopk(X, C, metric="neg_sq_l2", k=1, exclude_self=False)
-    return idx[:, 0], (-val[:, 0]).clamp_min_(0.0)
+def sklearn_stream(seed: int, n_init: int, n_clusters: int, n_samples: int) -> Tuple[np.ndarray, np.ndarray]:
+    """scikit-learn's draws for KMeans(n_clusters, random_state=seed, n_init=n_init) on n_samples points:
+    (first centre of every restart, int64 [n_init]; uniforms float64 [n_init, n_clusters - 1, trials]).
 
-
-def _kmeanspp(X: torch.Tensor, k: int, n_init: int, gen: torch.Generator) -> torch.Tensor:
-    """Greedy k-means++ (Arthur & Vassilvitskii, with 2 + log k local trials per step) for ALL n_init seedings in
-    lockstep, inside the library (``mmf_kmeanspp_seed``): per step one kernel draws every seeding's trial candidates, one
-    forms their clamped distance rows and potentials, one keeps the best trial — the k - 1 steps are enqueued by a single
-    call and nothing returns to the host (one seeding at a time with a `.item()` per step was 85 % of a fit; the same
-    lockstep in a dozen torch ops per step was still launch-bound: 22 ms at N = 16384).  The uniforms come from the
-    caller's generator.  Returns the centres, [n_init, k, D]."""
-    trials = 2 + int(math.log(k))
-    u_first = torch.rand(n_init, generator=gen, device=X.device)
-    u_steps = torch.rand((k - 1, n_init, trials), generator=gen, device=X.device)
-    return X[ops.kmeanspp_seed(X, k, u_first, u_steps)].contiguous()
+    The first centre is ``RandomState.choice(n, p=ones(n, float32) / float32(n))``: one ``random_sample()`` looked up
+    (side='right') in the normalised float64 cumulative sum of p (numpy/random/mtrand.pyx)."""
+    trials = 2 + int(math.log(n_clusters))
+    rs = np.random.RandomState(seed)
+    p = (np.ones(n_samples, np.float32) / np.float32(n_samples)).astype(np.float64)
+    cdf = p.cumsum()
+    cdf /= cdf[-1]
+    first = np.empty(n_init, np.int64)
+    u = np.empty((n_init, max(n_clusters - 1, 0), trials), np.float64)
+    for i in range(n_init):
+        first[i] = cdf.searchsorted(rs.random_sample(), side="right")
+        for c in range(n_clusters - 1):
+            u[i, c] = rs.uniform(size=trials)
+    np.clip(first, 0, n_samples - 1, out=first)
+    return first, u
 
 
 def kmeans_fit_predict(X: torch.Tensor, n_clusters: int, *, n_init: int = 10, max_iter: int = 300,
-                       tol: float = 1e-4, seed: int = 42) -> Tuple[torch.Tensor, torch.Tensor, float]:
-    """Returns (labels int64 [N], centers f32 [k, D], inertia).  X must live on a ROCm device."""
+                       tol: float = 1e-4, seed: int = 42, return_info: bool = False):
+    """Returns (labels int64 [N], centers f32 [k, D], inertia) — the labels of
+    ``KMeans(n_clusters, random_state=seed, n_init=n_init, max_iter=max_iter, tol=tol).fit_predict(X)``.
+    X must live on a ROCm device."""
     if not X.is_cuda:
         raise RuntimeError("kmeans_fit_predict: X must be on a ROCm device (no CPU path)")
     X = X.detach().float().contiguous()
-    n, d = X.shape
+    n = X.shape[0]
     if not (1 <= n_clusters <= n):
         raise ValueError(f"n_samples={n} should be >= n_clusters={n_clusters}.")
-    mean = X.mean(dim=0, keepdim=True)
-    Xc = X - mean                                                             # as sklearn: better conditioned
-    tol_abs = float(tol) * float(Xc.var(dim=0, unbiased=False).mean())
-    gen = torch.Generator(device=X.device).manual_seed(int(seed))
-    C = _kmeanspp(Xc, n_clusters, n_init, gen)                                # [n_init, k, D]
-    # lockstep while the [n_init * k, N] distance rows stay within 512 MiB (measured with the tiled distance kernel:
-    # N = 65536, k = 100: 61 -> 40 ms per fit; 10 groups of 100 rows: 8 -> 2 ms); beyond that restart by restart
-    if n_init * n_clusters <= 16384 and n_init * n_clusters * n <= (1 << 27):
-        labels, C, inertia = _lloyd_lockstep(Xc, C, max_iter, tol_abs)
-    else:
-        labels, C, inertia = _lloyd_one_by_one(Xc, C, max_iter, tol_abs)
-    return labels, C + mean, inertia
-
-
-def _lloyd_lockstep(Xc: torch.Tensor, C: torch.Tensor, max_iter: int, tol_abs: float):
-    """All restarts iterate together: one kernel forms the distance rows of every restart's centroids
-    (``mmf_seed_distances`` with explicit rows), one counting sort groups the members of all n_init * k clusters, one
-    segmented mean updates all centroids — a dozen launches and two host round trips per iteration for ALL restarts
-    (one restart at a time: that many per restart).  A restart that has converged keeps iterating at its fixed point
-    until the last one has."""
-    I, k, d = C.shape
-    n = Xc.shape[0]
-    base = (torch.arange(I, device=Xc.device) * k)[:, None]
-    def assign(C):
-        D = ops.seed_distances(Xc, C.reshape(I * k, d)).view(I, k, n)
-        d2, lab = D.min(dim=1)                                                # [I, n]
-        return lab, d2
-    for _it in range(max_iter):
-        lab, d2 = assign(C)
-        seg = ops.segment_sort((lab + base).reshape(-1), I * k)               # members of all I * k clusters
-        rows = ops.Segments(seg.counts, seg.offsets, seg.order % n, n, I * k)
-        newC = ops.segment_mean(Xc, rows).view(I, k, d)
-        empty = (seg.counts == 0).view(I, k)
-        shift = ((newC - C) ** 2).sum(dim=(1, 2))
-        any_empty, done = torch.stack([empty.any(), (shift <= tol_abs).all()]).tolist()
-        if any_empty:                                                         # relocate empty clusters to the points
-            for i in torch.nonzero(empty.any(dim=1)).flatten().tolist():      # farthest from their centre
-                far = torch.topk(d2[i], int(empty[i].sum())).indices
-                newC[i][empty[i]] = Xc[far]
-            done = False
-        C = newC
-        if done:
-            break
-    lab, d2 = assign(C)
-    inertia = d2.sum(dim=1)
-    best = int(torch.argmin(inertia))
-    return lab[best].contiguous(), C[best], float(inertia[best])
-
-
-def _lloyd_one_by_one(Xc: torch.Tensor, seeds: torch.Tensor, max_iter: int, tol_abs: float):
-    """Large problems: one restart at a time, assignment by the fused similarity + top-1 scan, which never stores the
-    N x k matrix (and stops each restart at its own convergence)."""
-    n_clusters = seeds.shape[1]
-    best = None
-    for init in range(seeds.shape[0]):
-        C = seeds[init]
-        labels = None
-        for _it in range(max_iter):
-            labels, d2 = _assign(Xc, C)
-            seg = ops.segment_sort(labels, n_clusters)
-            newC = ops.segment_mean(Xc, seg)
-            empty = seg.counts == 0
-            if bool(empty.any()):                                            # relocate empty clusters to the
-                far = torch.topk(d2, int(empty.sum())).indices               # points farthest from their centre
-                newC[empty] = Xc[far]
-            shift = float(((newC - C) ** 2).sum())
-            C = newC
-            if shift <= tol_abs:
-                break
-        labels, d2 = _assign(Xc, C)
-        inertia = float(d2.sum())
-        if best is None or inertia < best[2]:
-            best = (labels, C, inertia)
-    return best
+    first, u = sklearn_stream(int(seed), int(n_init), int(n_clusters), n)
+    labels, centres, info = ops.kmeans_fit(X, n_clusters, first, u, max_iter=max_iter, tol=tol)
+    if return_info:
+        return labels, centres, info["inertia"], info
+    return labels, centres, info["inertia"]

@@ -484,3 +484,37 @@ def kmeanspp_seed(X: torch.Tensor, k: int, u_first: torch.Tensor, u_steps: torch
                                       X.device.index or 0, _stream(X.device))
     _lib.check(rc, "mmf_kmeanspp_seed")
     return out
+
+
+def kmeans_fit(X: torch.Tensor, n_clusters: int, first_centres, uniforms, *, max_iter: int = 300, tol: float = 1e-4,
+               return_seeds: bool = False):
+    """scikit-learn's KMeans fit on the device, decision for decision (mmf_kmeans_fit).  X f32 [n, d] on the GPU;
+    first_centres: int64 [n_init] and uniforms: float64 [n_init, n_clusters - 1, trials] are HOST (numpy) arrays holding
+    scikit-learn's random stream (multimodal-fusion_amd/kmeans.py draws them).  Returns (labels int64 [n],
+    centres f32 [n_clusters, d], info dict[, seeds int64 [n_init, n_clusters]])."""
+    import numpy as np
+    X = _feat(X, "kmeans_fit X").float()
+    _need_gpu(X, "kmeans_fit")
+    n, d = X.shape
+    first = np.ascontiguousarray(first_centres, dtype=np.int64)
+    n_init = int(first.shape[0])
+    k = int(n_clusters)
+    u = np.ascontiguousarray(uniforms, dtype=np.float64)
+    if k > 1 and (u.ndim != 3 or u.shape[0] != n_init or u.shape[1] != k - 1):
+        raise ValueError("kmeans_fit: uniforms must be [n_init, n_clusters - 1, trials]")
+    trials = int(u.shape[2]) if k > 1 else 1
+    labels = torch.empty(n, dtype=torch.int64, device=X.device)
+    centres = torch.empty((k, d), dtype=torch.float32, device=X.device)
+    seeds = torch.empty((n_init, k), dtype=torch.int64, device=X.device) if return_seeds else None
+    info = np.zeros(7 + 2 * n_init, dtype=np.float64)
+    rc = _lib.lib().mmf_kmeans_fit(_p(X), n, d, k, n_init, trials, ctypes.c_void_p(first.ctypes.data),
+                                   ctypes.c_void_p(u.ctypes.data) if k > 1 else None, int(max_iter), float(tol), _p(labels),
+                                   _p(centres), _p(seeds), ctypes.c_void_p(info.ctypes.data), X.device.index or 0,
+                                   _stream(X.device))
+    _lib.check(rc, "mmf_kmeans_fit")
+    out_info = {"best_init": int(info[0]), "inertia": float(info[1]), "n_iter": int(info[2]), "tol_abs": float(info[3]),
+                "ambiguous_draws": int(info[4]), "ambiguous_trials": int(info[5]), "lockstep_iterations": int(info[6]),
+                "inertia_per_init": info[7::2].tolist(), "n_iter_per_init": [int(v) for v in info[8::2]]}
+    if return_seeds:
+        return labels, centres, out_info, seeds
+    return labels, centres, out_info

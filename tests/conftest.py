@@ -33,14 +33,15 @@ def unit_rows(n, d, seed):
     return x / x.norm(dim=1, keepdim=True)
 
 
-@pytest.fixture()
-def sklearn_kmeans():
-    """Run the mirrors' KMeans steps through the reference's own scikit-learn call, so labels — and the edges built on
-    them — can be compared with the fixtures the reference produced.  (The default backend is the device KMeans.)"""
+@pytest.fixture(params=["device", "sklearn"])
+def kmeans_backend(request):
+    """Run a mirror test once per KMeans backend: the default device KMeans (csrc/mmf_kmeans.hip: scikit-learn's fit,
+    decision for decision) and the reference's own scikit-learn call on the host.  Both must reproduce the fixtures the
+    reference produced (labels, and the edges built on them)."""
     from importlib import import_module
     import multimodal_fusion_amd  # noqa: F401
     pp = import_module("multimodal_fusion_amd.build_hypergraph.preprocess_hypergraph")
     prev = pp.KMEANS_BACKEND
-    pp.set_kmeans_backend("sklearn")
-    yield pp
+    pp.set_kmeans_backend(request.param)
+    yield request.param
     pp.set_kmeans_backend(prev)

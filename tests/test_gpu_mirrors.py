@@ -94,7 +94,7 @@ def test_compute_wsi_tma_similarity(bh, N, M):
 
 
 @pytest.mark.parametrize("tag", ["small", "mid", "zero"])
-def test_build_hypergraph_knn_kmeans(bh, tag, sklearn_kmeans):
+def test_build_hypergraph_knn_kmeans(bh, tag, kmeans_backend):
     g = load_golden("g5_knn_kmeans.npz")
     W, Tm = T(g[f"{tag}_W"]), T(g[f"{tag}_T"])
     k, H = int(g[f"{tag}_k"]), int(g[f"{tag}_H"])
@@ -117,7 +117,7 @@ def test_build_hypergraph_knn_kmeans(bh, tag, sklearn_kmeans):
         bh.build_hypergraph_knn_kmeans(W[:3], Tm[:2], None, 5, 2)
 
 
-def test_aggregate_and_group(bh, sklearn_kmeans):
+def test_aggregate_and_group(bh, kmeans_backend):
     g = load_golden("g1_dense.npz")
     X, P = T(g["N256_D128_X"]), T(g["N256_D128_P2"])
     sf, sp, st, K = bh.aggregate_wsi_super_patches(X, P, 8)

@@ -222,7 +222,7 @@ def _edges_sorted(f):
     return e[:, order], f["hypergraph/edge_weights"][:][order]
 
 
-def test_pipelines_reproduce_the_reference_arithmetic(bh_store, sklearn_kmeans):
+def test_pipelines_reproduce_the_reference_arithmetic(bh_store, kmeans_backend):
     """process_single_file, then rebuild_hypergraph_from_similarity with other parameters and the edge-weight median
     filter, against golden G8."""
     b, store = bh_store
