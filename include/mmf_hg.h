@@ -340,31 +340,6 @@ int mmf_combined_threshold_edges(const float* F, const float* P, int64_t n, int6
  *                             already holds it.  pair_lo / pair_hi need room for n * k; order unspecified.
  */
 /*
- * The distance rows of the device KMeans that stands in for the reference's
- * KMeans(n_clusters, random_state=42, n_init=10).fit_predict (preprocess_hypergraph.py:150-151, 299-300, 391-392):
- *   out[r][i] = min(closest[r / group][i], |x_i - c_r|^2)   r < n_cand, i < n
- * squared distances of every row of X[n, d] (f32) to n_cand candidate rows c_r: rows of X picked by cand[r]
- * (k-means++ seeding: the trial candidates of several independent seedings side by side, `group` per seeding, clamped
- * by each seeding's running distance to its closest chosen centre, closest: [ceil(n_cand / group), n]) or, when
- * cand_rows != NULL, the rows of that [n_cand, d] matrix (the centroids of all restarts at once: the assignment step;
- * closest == NULL: no clamp).  Direct differences, fixed summation tree: deterministic.
- */
-int mmf_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
-                       int64_t group, const float* closest, float* out, int device_id, void* hip_stream);
-
-/*
- * Greedy k-means++ seeding (Arthur & Vassilvitskii, `trials` candidates per step, the best one kept) for n_init
- * independent seedings in lockstep — the initialisation of the same KMeans calls.  The caller supplies the randomness:
- * u_first[n_init] and u_steps[k - 1][n_init][trials], uniforms in [0, 1) (device f32).  Step s draws every seeding's
- * trial candidates with probability proportional to its running closest-centre distance (inverse-CDF sampling, f64
- * sums in a fixed order), forms their clamped distance rows and potentials, and keeps the trial with the smallest
- * potential: three launches per step, all k - 1 steps enqueued by this one call, nothing returns to the host.
- * centre_idx[n_init][k] (device int64): the rows of X chosen as initial centres.  Deterministic.
- */
-int mmf_kmeanspp_seed(const float* X, int64_t n, int64_t d, int64_t k, int64_t n_init, int trials, const float* u_first,
-                      const float* u_steps, int64_t* centre_idx, int device_id, void* hip_stream);
-
-/*
  * The reference's clustering call, KMeans(n_clusters, random_state=seed, n_init=n_init).fit_predict(X)
  * (build_hypergraph/preprocess_hypergraph.py:150-151, 299-300, 391-392), on the device and DECISION FOR DECISION:
  * scikit-learn's k-means++ seeding, Lloyd iterations, convergence tests and choice of the best restart

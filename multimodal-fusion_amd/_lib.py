@@ -47,7 +47,7 @@ _lib = None
 EXPORTS = ["mmf_version", "mmf_last_error", "mmf_simtopk", "mmf_simtopk_ex", "mmf_row_scalars", "mmf_prep_rows",
            "mmf_simtopk_prepared", "mmf_simtopk_panels", "mmf_padded_dim", "mmf_fast_scan_supported", "mmf_topk_merge", "mmf_edge_cosine",
            "mmf_sim_dense", "mmf_sim_dense_stats", "mmf_sim_dense_combined", "mmf_offdiag_lower_median", "mmf_threshold_edges", "mmf_lower_median", "mmf_array_stats",
-           "mmf_segment_sort", "mmf_segment_mean", "mmf_segment_offdiag_mean", "mmf_clique_pairs", "mmf_knn_pairs", "mmf_seed_distances", "mmf_kmeanspp_seed", "mmf_kmeans_fit", "mmf_combined_offdiag_median", "mmf_combined_threshold_edges",
+           "mmf_segment_sort", "mmf_segment_mean", "mmf_segment_offdiag_mean", "mmf_clique_pairs", "mmf_knn_pairs", "mmf_kmeans_fit", "mmf_combined_offdiag_median", "mmf_combined_threshold_edges",
            "mmf_release_workspaces"]
 
 
@@ -87,8 +87,6 @@ def lib() -> ctypes.CDLL:
     L.mmf_segment_offdiag_mean.argtypes = [vp, i64, vp, vp, i64, vp, ci, vp]
     L.mmf_clique_pairs.argtypes = [vp, vp, i64, i64, vp, vp, i64, vp, ci, vp]
     L.mmf_knn_pairs.argtypes = [vp, i64, ci, vp, vp, vp, vp, ci, vp]
-    L.mmf_seed_distances.argtypes = [vp, i64, i64, vp, vp, i64, i64, vp, vp, ci, vp]
-    L.mmf_kmeanspp_seed.argtypes = [vp, i64, i64, i64, i64, ci, vp, vp, vp, ci, vp]
     L.mmf_kmeans_fit.argtypes = [vp, i64, i64, i64, i64, ci, vp, vp, ci, ctypes.c_double, vp, vp, vp, vp, ci, vp]
     L.mmf_lower_median.argtypes = [vp, i64, vp, ci, vp]
     L.mmf_array_stats.argtypes = [vp, i64, vp, ci, vp]

@@ -968,36 +968,6 @@ int mmf_knn_pairs(const int64_t* nbr, int64_t n, int k, const int64_t* labels, i
   return launch_knn_pairs(nbr, n, k, labels, pair_lo, pair_hi, out_count, static_cast<hipStream_t>(hip_stream));
 }
 
-int mmf_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
-                       int64_t group, const float* closest, float* out, int device_id, void* hip_stream) {
-  if (device_id < 0) { set_error("seed_distances: no CPU path"); return MMF_E_UNSUPPORTED; }
-  if (n < 0 || d < 1 || n_cand < 0 || group < 1) { set_error("seed_distances: bad n / d / n_cand / group"); return MMF_E_INVALID; }
-  if (d > seed_distances_max_dim()) { set_error("seed_distances: d = %lld above the supported %d", (long long)d, seed_distances_max_dim()); return MMF_E_UNSUPPORTED; }
-  if (n > 0 && n_cand > 0 && (!X || (!cand && !cand_rows) || !out)) { set_error("seed_distances: NULL pointer"); return MMF_E_INVALID; }
-  DeviceGuard guard(device_id);
-  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
-  return launch_seed_distances(X, n, d, cand, cand_rows, n_cand, group, closest, out, static_cast<hipStream_t>(hip_stream));
-}
-
-int mmf_kmeanspp_seed(const float* X, int64_t n, int64_t d, int64_t k, int64_t n_init, int trials, const float* u_first,
-                      const float* u_steps, int64_t* centre_idx, int device_id, void* hip_stream) {
-  if (device_id < 0) { set_error("kmeanspp_seed: no CPU path"); return MMF_E_UNSUPPORTED; }
-  if (n < 1 || d < 1 || k < 1 || k > n || n_init < 1 || trials < 1 || trials > 1024) {
-    set_error("kmeanspp_seed: need 1 <= k <= n, n_init >= 1, 1 <= trials <= 1024 (n = %lld, k = %lld, n_init = %lld, trials = %d)",
-              (long long)n, (long long)k, (long long)n_init, trials);
-    return MMF_E_INVALID;
-  }
-  if (d > seed_distances_max_dim()) { set_error("kmeanspp_seed: d = %lld above the supported %d", (long long)d, seed_distances_max_dim()); return MMF_E_UNSUPPORTED; }
-  if (!X || !u_first || (k > 1 && !u_steps) || !centre_idx) { set_error("kmeanspp_seed: NULL pointer"); return MMF_E_INVALID; }
-  hipStream_t s = static_cast<hipStream_t>(hip_stream);
-  DeviceGuard guard(device_id);
-  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
-  const size_t need = kmeanspp_scratch_bytes(n, n_init, trials);
-  Workspace ws;
-  MMF_TRY(get_workspace(device_id, s, ws_bytes(need, 1), &ws));
-  return launch_kmeanspp(X, n, d, k, n_init, trials, u_first, u_steps, centre_idx, ws.take<char>(need), s);
-}
-
 int mmf_kmeans_fit(const float* X, int64_t n, int64_t d, int64_t n_clusters, int64_t n_init, int trials, const int64_t* first_centres,
                    const double* uniforms, int max_iter, double tol, int64_t* labels, float* centres, int64_t* seeds, double* info,
                    int device_id, void* hip_stream) {

@@ -37,23 +37,14 @@ __device__ __forceinline__ f32x4 dload4(const void* base, int64_t row, int64_t k
   return v;
 }
 
-// What the seeding / assignment steps of the device KMeans ask of the same tile loop (EPI_SEED): the raw squared
-// distances, rows of X picked by index as the left operand, a clamp by a running closest-centre distance, and per-row
-// partial sums (one per 128-column tile) for the potentials.
-struct SeedArgs {
-  const int64_t* row_idx;     // left operand row i = X[row_idx[i]] (NULL: row i of X)
-  const float* closest;       // [ceil(n / group)][m] or NULL
-  int64_t group;
-  double* partial;            // [n][column tiles] or NULL
-};
-constexpr int EPI_EXP = 0, EPI_EXP_STATS = 1, EPI_SEED = 2;
+constexpr int EPI_EXP = 0, EPI_EXP_STATS = 1;
 
 // X: rows [xrow0, xrow0 + n) of the query matrix are this launch's rows; out (may be null) has leading dimension m.
 template <bool VEC4, int EPI>
 __global__ __launch_bounds__(256, 3) void rbf_direct_tiled_kernel(const void* __restrict__ X, int64_t n, const void* __restrict__ Y,
                                                                int64_t m, int64_t d, int dtype, float neg_lambda,
                                                                float* __restrict__ out, StatPartial* __restrict__ part,
-                                                               const float* __restrict__ pivot, SeedArgs sa) {
+                                                               const float* __restrict__ pivot) {
   constexpr bool STATS = (EPI == EPI_EXP_STATS);
   __shared__ __attribute__((aligned(16))) float As[2][D_KC][D_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][D_KC][D_LD];
@@ -67,9 +58,6 @@ __global__ __launch_bounds__(256, 3) void rbf_direct_tiled_kernel(const void* __
   for (int i = 0; i < 2; ++i) {
     xr[i] = i0 + srow + 64 * i; if (xr[i] > n - 1) xr[i] = n - 1;
     yr[i] = j0 + srow + 64 * i; if (yr[i] > m - 1) yr[i] = m - 1;
-    if constexpr (EPI == EPI_SEED) {
-      if (sa.row_idx) xr[i] = sa.row_idx[xr[i]];
-    }
   }
   f32x4 ra[2], rb[2];
   auto gload = [&](int64_t k0) {
@@ -124,42 +112,6 @@ __global__ __launch_bounds__(256, 3) void rbf_direct_tiled_kernel(const void* __
     __syncthreads();
   }
 
-  if constexpr (EPI == EPI_SEED) {
-    // raw squared distances, clamped; a row's 128 values of this tile summed in column order within a lane, then over the
-    // 16 lanes that share the row (a fixed butterfly)
-    const bool vst = ((m & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int64_t row = i0 + ty * 8 + i;
-      float rs = 0.0f;
-      if (row < n) {
-        const float* cl = sa.closest ? sa.closest + (row / sa.group) * m : nullptr;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int64_t col = j0 + 64 * h + tx * 4;
-          f32x4 v;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            v[j] = acc[i][4 * h + j];
-            if (cl && col + j < m) v[j] = fminf(v[j], cl[col + j]);
-            if (col + j < m) rs += v[j];
-          }
-          if (vst && col + 3 < m) *reinterpret_cast<f32x4*>(out + row * m + col) = v;
-          else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (col + j < m) out[row * m + col + j] = v[j];
-          }
-        }
-      }
-      if (sa.partial) {
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) rs += __shfl_xor(rs, o);
-        if (tx == 0 && row < n) sa.partial[row * (int64_t)gridDim.x + blockIdx.x] = (double)rs;
-      }
-    }
-    return;
-  }
   // epilogue: exp, 16-byte stores (the 16 lanes of a row group cover 256 contiguous bytes twice), statistics
   double s1 = 0.0, s2 = 0.0;
   float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
@@ -245,124 +197,12 @@ int launch_rbf_direct(const void* X, int64_t n, const void* Y, int64_t m, int64_
   StatPartial* sp = reinterpret_cast<StatPartial*>(part);
   const bool v4 = direct_vec4(X, Y, d, dtype);
   if (part) {
-    if (v4) hipLaunchKernelGGL((rbf_direct_tiled_kernel<true, EPI_EXP_STATS>), grid, dim3(256), 0, s, X, n, Y, m, d, dtype, -lambda, out, sp, pivot, SeedArgs{});
-    else hipLaunchKernelGGL((rbf_direct_tiled_kernel<false, EPI_EXP_STATS>), grid, dim3(256), 0, s, X, n, Y, m, d, dtype, -lambda, out, sp, pivot, SeedArgs{});
+    if (v4) hipLaunchKernelGGL((rbf_direct_tiled_kernel<true, EPI_EXP_STATS>), grid, dim3(256), 0, s, X, n, Y, m, d, dtype, -lambda, out, sp, pivot);
+    else hipLaunchKernelGGL((rbf_direct_tiled_kernel<false, EPI_EXP_STATS>), grid, dim3(256), 0, s, X, n, Y, m, d, dtype, -lambda, out, sp, pivot);
   } else {
-    if (v4) hipLaunchKernelGGL((rbf_direct_tiled_kernel<true, EPI_EXP>), grid, dim3(256), 0, s, X, n, Y, m, d, dtype, -lambda, out, sp, pivot, SeedArgs{});
-    else hipLaunchKernelGGL((rbf_direct_tiled_kernel<false, EPI_EXP>), grid, dim3(256), 0, s, X, n, Y, m, d, dtype, -lambda, out, sp, pivot, SeedArgs{});
+    if (v4) hipLaunchKernelGGL((rbf_direct_tiled_kernel<true, EPI_EXP>), grid, dim3(256), 0, s, X, n, Y, m, d, dtype, -lambda, out, sp, pivot);
+    else hipLaunchKernelGGL((rbf_direct_tiled_kernel<false, EPI_EXP>), grid, dim3(256), 0, s, X, n, Y, m, d, dtype, -lambda, out, sp, pivot);
   }
-  MMF_LAUNCH_CHECK();
-  return MMF_OK;
-}
-
-// The seeding epilogue on 64 x 64 tiles, 4 x 4 outputs per lane: for launches too small to fill the chip with 128 x 128
-// tiles (a k-means++ step at N = 16384 is 60 candidate rows = 128 such tiles, each of them 107 us of work wherever it runs).
-constexpr int S_B = 64, S_LD = 68;
-template <bool VEC4>
-__global__ __launch_bounds__(256) void seed_tile64_kernel(const float* __restrict__ A, int64_t n, const float* __restrict__ Y, int64_t m,
-                                                          int64_t d, float* __restrict__ out, SeedArgs sa) {
-  __shared__ __attribute__((aligned(16))) float As[2][D_KC][S_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][D_KC][S_LD];
-  const int tid = threadIdx.x;
-  const int tx = tid & 15, ty = tid >> 4;
-  const int64_t i0 = (int64_t)blockIdx.y * S_B, j0 = (int64_t)blockIdx.x * S_B;
-  const int srow = tid >> 2, sk = (tid & 3) * 4;
-  int64_t xr = i0 + srow, yr = j0 + srow;
-  if (xr > n - 1) xr = n - 1;
-  if (yr > m - 1) yr = m - 1;
-  if (sa.row_idx) xr = sa.row_idx[xr];
-  f32x4 ra, rb;
-  auto gload = [&](int64_t k0) {
-    ra = dload4<VEC4>(A, xr, k0 + sk, d, MMF_F32);
-    rb = dload4<VEC4>(Y, yr, k0 + sk, d, MMF_F32);
-  };
-  auto swrite = [&](int buf) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { As[buf][sk + e][srow] = ra[e]; Bs[buf][sk + e][srow] = rb[e]; }
-  };
-  float acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
-  const int nk = (int)((d + D_KC - 1) / D_KC);
-  gload(0);
-  swrite(0);
-  __syncthreads();
-  for (int s = 0; s < nk; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nk) gload((int64_t)(s + 1) * D_KC);
-#pragma unroll 4
-    for (int k = 0; k < D_KC; ++k) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(&As[buf][k][ty * 4]);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[buf][k][tx * 4]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float t = a[i] - b[j];
-          acc[i][j] = __builtin_fmaf(t, t, acc[i][j]);
-        }
-    }
-    if (s + 1 < nk) swrite(buf ^ 1);
-    __syncthreads();
-  }
-  const bool vst = ((m & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t row = i0 + ty * 4 + i;
-    float rs = 0.0f;
-    if (row < n) {
-      const float* cl = sa.closest ? sa.closest + (row / sa.group) * m : nullptr;
-      const int64_t col = j0 + tx * 4;
-      f32x4 v;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[j] = acc[i][j];
-        if (cl && col + j < m) v[j] = fminf(v[j], cl[col + j]);
-        if (col + j < m) rs += v[j];
-      }
-      if (vst && col + 3 < m) *reinterpret_cast<f32x4*>(out + row * m + col) = v;
-      else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (col + j < m) out[row * m + col + j] = v[j];
-      }
-    }
-    if (sa.partial) {
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) rs += __shfl_xor(rs, o);
-      if (tx == 0 && row < n) sa.partial[row * (int64_t)gridDim.x + blockIdx.x] = (double)rs;
-    }
-  }
-}
-
-// out[r][i] = min(closest[r / group][i], |x_i - c_r|^2) for n_cand candidate rows c_r (rows of X by index, or explicit rows)
-// against all n rows of X; partial (optional): [n_cand][seed_tiles(n, n_cand)] sums of the clamped rows per column tile.
-static int seed_tile_width(int64_t n, int64_t n_cand) {
-  const int64_t big = ((n + D_BN - 1) / D_BN) * ((n_cand + D_BM - 1) / D_BM);
-  // few 128 x 128 tiles: 64 x 64 ones fill the chip and finish sooner; up to 64 candidate rows: a 128-row tile would
-  // spend half its work on padding
-  return (big < 512 || n_cand <= S_B) ? S_B : D_BN;
-}
-int64_t seed_tiles(int64_t n, int64_t n_cand) { const int w = seed_tile_width(n, n_cand); return (n + w - 1) / w; }
-int launch_seed_dists_tiled(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
-                            int64_t group, const float* closest, float* out, double* partial, hipStream_t s) {
-  if (n <= 0 || n_cand <= 0) return MMF_OK;
-  const float* A = cand_rows ? cand_rows : X;
-  SeedArgs sa{cand_rows ? nullptr : cand, closest, group, partial};
-  if (seed_tile_width(n, n_cand) == S_B) {
-    const dim3 g64((unsigned)((n + S_B - 1) / S_B), (unsigned)((n_cand + S_B - 1) / S_B));
-    if (direct_vec4(A, X, d, MMF_F32)) hipLaunchKernelGGL(seed_tile64_kernel<true>, g64, dim3(256), 0, s, A, n_cand, X, n, d, out, sa);
-    else hipLaunchKernelGGL(seed_tile64_kernel<false>, g64, dim3(256), 0, s, A, n_cand, X, n, d, out, sa);
-    MMF_LAUNCH_CHECK();
-    return MMF_OK;
-  }
-  const dim3 grid((unsigned)((n + D_BN - 1) / D_BN), (unsigned)((n_cand + D_BM - 1) / D_BM));
-  if (direct_vec4(A, X, d, MMF_F32))
-    hipLaunchKernelGGL((rbf_direct_tiled_kernel<true, EPI_SEED>), grid, dim3(256), 0, s, A, n_cand, X, n, d, MMF_F32, 0.0f, out, nullptr, nullptr, sa);
-  else
-    hipLaunchKernelGGL((rbf_direct_tiled_kernel<false, EPI_SEED>), grid, dim3(256), 0, s, A, n_cand, X, n, d, MMF_F32, 0.0f, out, nullptr, nullptr, sa);
   MMF_LAUNCH_CHECK();
   return MMF_OK;
 }

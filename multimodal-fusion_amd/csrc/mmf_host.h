@@ -219,15 +219,6 @@ int launch_segment_offdiag_mean(const float* K, int64_t n, const int64_t* order,
 size_t clique_scratch_bytes(int64_t n, int64_t S);
 int launch_clique_pairs(const int64_t* order, const int64_t* offsets, int64_t n, int64_t S, int64_t* lo, int64_t* hi,
                         int64_t capacity, int64_t* out_count, void* scratch, hipStream_t s);
-int seed_distances_max_dim();
-int64_t seed_tiles(int64_t n, int64_t n_cand);   // mmf_direct.hip: column tiles of the seeding-distance launch for this shape
-int launch_seed_dists_tiled(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
-                            int64_t group, const float* closest, float* out, double* partial, hipStream_t s);
-int launch_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
-                          int64_t group, const float* closest, float* out, hipStream_t s);
-size_t kmeanspp_scratch_bytes(int64_t n, int64_t n_init, int trials);
-int launch_kmeanspp(const float* X, int64_t n, int64_t d, int64_t k, int64_t n_init, int trials, const float* U0, const float* U,
-                    int64_t* cidx, void* scratch, hipStream_t s);
 // mmf_kmeans.hip: scikit-learn's KMeans fit, decision for decision, all restarts in lockstep (host-synchronous)
 size_t kmeans_scratch_bytes(int64_t n, int64_t d, int64_t k, int64_t n_init, int trials);
 int launch_kmeans_fit(const float* X, int64_t n, int64_t d, int64_t k, int64_t n_init, int trials, const int64_t* first_h,

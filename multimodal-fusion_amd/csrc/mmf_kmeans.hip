@@ -88,42 +88,48 @@ __global__ void km_colfin_kernel(const double* __restrict__ partial, int64_t nbl
 }
 
 // mean32[col] = (((x_0 + x_1) + x_2) + ... ) / float32(n): the float32 row-by-row accumulation numpy's X.mean(axis=0) performs
-// on a C-contiguous float32 matrix, so the centred data are scikit-learn's bit for bit.  A sequential chain per column: one
-// workgroup per 64 columns stages 64 x 64 tiles through LDS (all 256 threads load, the next tile's loads in flight) and its
-// first wave walks the rows.
+// on a C-contiguous float32 matrix, so the centred data are scikit-learn's bit for bit.  A chain of n dependent adds per column is
+// latency, not bandwidth: a workgroup owns 8 columns (d / 8 workgroups keep enough loads in flight), stages chunks of 512 rows
+// through LDS — all 256 threads load, the next chunk's loads are in flight while the chain runs — and 8 lanes walk the rows.
+constexpr int CM_COLS = 8, CM_ROWS = 512;
 __global__ __launch_bounds__(256) void km_colmean_seq_kernel(const float* __restrict__ X, int64_t n, int64_t d, float* __restrict__ mean32) {
-  __shared__ float tile[64][64];
-  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int64_t col = (int64_t)blockIdx.x * 64 + c;
+  __shared__ float tile[CM_ROWS][CM_COLS];
+  const int c = threadIdx.x & (CM_COLS - 1), q = threadIdx.x / CM_COLS;      // q in [0, 32)
+  const int64_t col = (int64_t)blockIdx.x * CM_COLS + c;
   const bool live = col < d;
   float regs[16];
   float acc = 0.f;
-  const int64_t nchunks = (n + 63) / 64;
+  const int64_t nchunks = (n + CM_ROWS - 1) / CM_ROWS;
   auto load = [&](int64_t ch) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int64_t r = ch * 64 + q + 4 * i;
+      const int64_t r = ch * CM_ROWS + q + 32 * i;
       regs[i] = (live && r < n) ? X[r * d + col] : 0.f;
     }
   };
   load(0);
   for (int64_t ch = 0; ch < nchunks; ++ch) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) tile[q + 4 * i][c] = regs[i];
+    for (int i = 0; i < 16; ++i) tile[q + 32 * i][c] = regs[i];
     __syncthreads();
     if (ch + 1 < nchunks) load(ch + 1);
-    if (q == 0) {
-      const int64_t rows = (n - ch * 64 < 64) ? (n - ch * 64) : 64;
-      if (rows == 64) {
+    if (threadIdx.x < CM_COLS) {
+      const int64_t rows = (n - ch * CM_ROWS < CM_ROWS) ? (n - ch * CM_ROWS) : CM_ROWS;
+      if (rows == CM_ROWS) {
+        for (int r0 = 0; r0 < CM_ROWS; r0 += 32) {       // 32 LDS reads in flight, then the 32 dependent adds
+          float v[32];
 #pragma unroll
-        for (int r = 0; r < 64; ++r) acc += tile[r][c];
+          for (int u = 0; u < 32; ++u) v[u] = tile[r0 + u][c];
+#pragma unroll
+          for (int u = 0; u < 32; ++u) acc += v[u];
+        }
       } else {
         for (int r = 0; r < (int)rows; ++r) acc += tile[r][c];
       }
     }
     __syncthreads();
   }
-  if (q == 0 && live) mean32[col] = acc / (float)n;
+  if (threadIdx.x < CM_COLS && live) mean32[col] = acc / (float)n;
 }
 
 __global__ __launch_bounds__(1024) void km_tol_kernel(const double* __restrict__ var, int64_t d, double tol, double* __restrict__ tol_abs) {
@@ -191,70 +197,81 @@ __device__ __forceinline__ void km_stage_store(double* dst, const float4& v) {
   *reinterpret_cast<f64x2*>(dst + 2) = b;
 }
 
-// rowp[2] / ptp[2]: this thread's two staging rows (row t >> 3 and 32 + (t >> 3) of the tile) at column 4 (t & 7)
+// rowp[2] / ptp[2]: this thread's two staging rows (row t >> 3 and 32 + (t >> 3) of the tile) at column 4 (t & 7).
+// MT = 16-row MFMA tiles per wave: 4 -> tile 64 rows x 64 points, wave w owns points 16 w .. against all rows; 2 -> tile 64 rows x
+// 32 points, wave w owns rows 32 (w & 1) .. and points 16 (w >> 1) .. (twice the workgroups when 64-point tiles would leave the
+// chip with one wave per SIMD and nothing to hide the global loads behind).  Global loads run TWO chunks ahead of the MFMAs.
+template <int MT>
 __device__ __forceinline__ void km_tile_dots(const float* const rowp[2], const float* const ptp[2], int64_t nchunks, double* As, double* Bs,
-                                             f64x4 acc[4]) {
+                                             f64x4 acc[MT]) {
+  constexpr int NB = MT / 2;                 // staging rows of the point tile per thread
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4;
   const int sr = t >> 3, sk = (t & 7) * 4;
-  float4 ra[2], rb[2];
+  const int arow0 = (MT == 4) ? 0 : 32 * (w & 1);
+  const int bpt = (MT == 4) ? 16 * w : 16 * (w >> 1);
+  float4 ra[2][2], rb[2][NB];
+  auto gload = [&](int st, int64_t c) {
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    ra[u] = *reinterpret_cast<const float4*>(rowp[u]);
-    rb[u] = *reinterpret_cast<const float4*>(ptp[u]);
-  }
+    for (int u = 0; u < 2; ++u) ra[st][u] = *reinterpret_cast<const float4*>(rowp[u] + c * KM_KC);
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    km_stage_store(As + (sr + 32 * u) * KM_LD + sk, ra[u]);
-    km_stage_store(Bs + (sr + 32 * u) * KM_LD + sk, rb[u]);
-  }
-  __syncthreads();
-  for (int64_t c = 0; c < nchunks; ++c) {
-    const int buf = (int)(c & 1);
-    const bool more = c + 1 < nchunks;
-    if (more) {
+    for (int u = 0; u < NB; ++u) rb[st][u] = *reinterpret_cast<const float4*>(ptp[u] + c * KM_KC);
+  };
+  auto swrite = [&](int st, int buf) {
+    double* An = As + buf * (KM_T * KM_LD);
+    double* Bn = Bs + buf * (KM_T * KM_LD);
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        ra[u] = *reinterpret_cast<const float4*>(rowp[u] + (c + 1) * KM_KC);
-        rb[u] = *reinterpret_cast<const float4*>(ptp[u] + (c + 1) * KM_KC);
-      }
-    }
-    const double* A = As + buf * (KM_T * KM_LD) + (lane & 15) * KM_LD + 2 * g;
-    const double* B = Bs + buf * (KM_T * KM_LD) + (16 * w + (lane & 15)) * KM_LD + 2 * g;
+    for (int u = 0; u < 2; ++u) km_stage_store(An + (sr + 32 * u) * KM_LD + sk, ra[st][u]);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) km_stage_store(Bn + (sr + 32 * u) * KM_LD + sk, rb[st][u]);
+  };
+  auto compute = [&](int buf) {
+    const double* A = As + buf * (KM_T * KM_LD) + (arow0 + (lane & 15)) * KM_LD + 2 * g;
+    const double* B = Bs + buf * (KM_T * KM_LD) + (bpt + (lane & 15)) * KM_LD + 2 * g;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f64x2 b = *reinterpret_cast<const f64x2*>(B + 8 * q);
-      f64x2 a[4];
+      f64x2 a[MT];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const f64x2*>(A + m * 16 * KM_LD + 8 * q);
+      for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const f64x2*>(A + m * 16 * KM_LD + 8 * q);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b.x, acc[m], 0, 0, 0);
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b.x, acc[m], 0, 0, 0);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b.y, acc[m], 0, 0, 0);
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b.y, acc[m], 0, 0, 0);
     }
-    if (more) {
-      double* An = As + (buf ^ 1) * (KM_T * KM_LD);
-      double* Bn = Bs + (buf ^ 1) * (KM_T * KM_LD);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        km_stage_store(An + (sr + 32 * u) * KM_LD + sk, ra[u]);
-        km_stage_store(Bn + (sr + 32 * u) * KM_LD + sk, rb[u]);
-      }
-    }
+  };
+  gload(0, 0);
+  if (nchunks > 1) gload(1, 1);
+  swrite(0, 0);
+  __syncthreads();
+  // chunk c is in LDS buffer c & 1, chunk c + 1 in register stage (c + 1) & 1; chunk c + 2 is requested into stage c & 1
+  for (int64_t c = 0; c < nchunks; c += 2) {
+    if (c + 2 < nchunks) gload(0, c + 2);
+    compute(0);
+    if (c + 1 < nchunks) swrite(1, 1);
+    __syncthreads();
+    if (c + 1 >= nchunks) break;
+    if (c + 3 < nchunks) gload(1, c + 3);
+    compute(1);
+    if (c + 2 < nchunks) swrite(0, 0);
     __syncthreads();
   }
 }
 
-// Seeding distances: out[r][i] = min(closest[r / group][i], float32(max(0, (-2 c_r.x_i + |c_r|^2) + |x_i|^2))) for the rows
-// c_r = Xc[cand[r]], r < R, and partial[r][tile] = sum of out[r][i] over the tile's points (f64).  closest == NULL: no clamp.
+// Seeding distances: out[r][i] = min(clamp_r[i], float32(max(0, (-2 c_r.x_i + |c_r|^2) + |x_i|^2))) for the rows c_r = Xc[cand[r]],
+// r < R, and partial[r][tile] = sum of out[r][i] over the tile's points (f64).  clamp_r = prev[sel[r / group]]: the running
+// closest-centre distances of r's restart, which are a ROW OF THE PREVIOUS STEP'S OUTPUT (the trial that won): nothing is copied.
+// prev == NULL: no clamp (the first centre).
+template <int MT>
 __global__ __launch_bounds__(256, 2) void km_seed_dots_kernel(const float* __restrict__ Xc, int64_t n, int64_t ds, const double* __restrict__ xx,
                                                               const int64_t* __restrict__ cand, int64_t R, int64_t group,
-                                                              const float* __restrict__ closest, float* __restrict__ out,
-                                                              double* __restrict__ partial) {
+                                                              const float* __restrict__ prev, const int* __restrict__ sel,
+                                                              float* __restrict__ out, double* __restrict__ partial) {
+  constexpr int PT = (MT == 4) ? 64 : 32;
   extern __shared__ double km_lds[];
   double* As = km_lds;
   double* Bs = km_lds + 2 * KM_T * KM_LD;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int64_t p0 = (int64_t)blockIdx.x * KM_T, r0 = (int64_t)blockIdx.y * KM_T;
+  const int64_t p0 = (int64_t)blockIdx.x * PT, r0 = (int64_t)blockIdx.y * KM_T;
   const float* rowp[2];
   const float* ptp[2];
 #pragma unroll
@@ -266,46 +283,63 @@ __global__ __launch_bounds__(256, 2) void km_seed_dots_kernel(const float* __res
     rowp[u] = Xc + cand[r] * ds + (t & 7) * 4;
     ptp[u] = Xc + p * ds + (t & 7) * 4;
   }
-  f64x4 acc[4];
+  // what the epilogue needs from memory is requested before the contraction: |c_r|^2 of this lane's rows, |x_p|^2 of its point
+  const int arow0 = (MT == 4) ? 0 : 32 * (w & 1);
+  const int bpt = (MT == 4) ? 16 * w : 16 * (w >> 1);
+  double cr[MT][4];
 #pragma unroll
-  for (int m = 0; m < 4; ++m) acc[m] = f64x4{0.0, 0.0, 0.0, 0.0};
-  km_tile_dots(rowp, ptp, ds / KM_KC, As, Bs, acc);
-  // epilogue through LDS: [64 rows][65] f32
-  float* T = reinterpret_cast<float*>(km_lds);
-  {
-    const int64_t p = p0 + 16 * w + (lane & 15);
-    const double xp = xx[p < n ? p : n - 1];
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int rl = 16 * m + 4 * v + (lane >> 4);
-        int64_t r = r0 + rl;
-        if (r >= R) r = R - 1;
-        const double cr = xx[cand[r]];
-        double dd = -2.0 * acc[m][v];
-        dd = dd + cr;
-        dd = dd + xp;
-        float f = (float)dd;
-        f = f > 0.f ? f : 0.f;
-        T[rl * 65 + 16 * w + (lane & 15)] = f;
-      }
-  }
-  __syncthreads();
+    for (int v = 0; v < 4; ++v) {
+      int64_t r = r0 + arow0 + 16 * m + 4 * v + (lane >> 4);
+      if (r >= R) r = R - 1;
+      cr[m][v] = xx[cand[r]];
+    }
+  const int64_t pq = p0 + bpt + (lane & 15);
+  const double xp = xx[pq < n ? pq : n - 1];
+  // ... and the clamp values of the 16 rows this wave finishes (wave w: rows 16 w .. 16 w + 15, lane = point)
   const int64_t p = p0 + lane;
+  const bool live = lane < PT && p < n;
+  float cl[16];
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    const int64_t r = r0 + 16 * w + rr;
+    cl[rr] = __builtin_huge_valf();
+    if (prev && live && r < R) cl[rr] = prev[(int64_t)sel[r / group] * n + p];
+  }
+  f64x4 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = f64x4{0.0, 0.0, 0.0, 0.0};
+  km_tile_dots<MT>(rowp, ptp, ds / KM_KC, As, Bs, acc);
+  // epilogue through LDS: [64 rows][PT + 1] f32
+  float* T = reinterpret_cast<float*>(km_lds);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int rl = arow0 + 16 * m + 4 * v + (lane >> 4);
+      double dd = -2.0 * acc[m][v];
+      dd = dd + cr[m][v];
+      dd = dd + xp;
+      float f = (float)dd;
+      f = f > 0.f ? f : 0.f;
+      T[rl * (PT + 1) + bpt + (lane & 15)] = f;
+    }
+  __syncthreads();
+  // wave w finishes rows 16 w .. 16 w + 15: clamp, store, tile sum
+#pragma unroll
   for (int rr = 0; rr < 16; ++rr) {
     const int rl = 16 * w + rr;
     const int64_t r = r0 + rl;
-    if (r >= R) break;
-    float f = T[rl * 65 + lane];
-    double s = 0.0;
-    if (p < n) {
-      if (closest) { const float cl = closest[(r / group) * n + p]; f = f < cl ? f : cl; }
+    double sm = 0.0;
+    if (live && r < R) {
+      float f = T[rl * (PT + 1) + lane];
+      f = f < cl[rr] ? f : cl[rr];
       out[r * n + p] = f;
-      s = (double)f;
+      sm = (double)f;
     }
-    s = wave_sum(s);
-    if (lane == 0) partial[r * gridDim.x + blockIdx.x] = s;
+    sm = wave_sum(sm);
+    if (lane == 0 && r < R) partial[r * gridDim.x + blockIdx.x] = sm;
   }
 }
 
@@ -343,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void km_assign_kernel(const float* __restri
     f64x4 acc[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = f64x4{0.0, 0.0, 0.0, 0.0};
-    km_tile_dots(rowp, ptp, ds / KM_KC, As, Bs, acc);
+    km_tile_dots<4>(rowp, ptp, ds / KM_KC, As, Bs, acc);
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -378,102 +412,136 @@ __global__ void km_seed_first_kernel(const int64_t* __restrict__ first, int64_t 
   cand[i] = first[i];
 }
 
-// One workgroup per restart: candidate of trial t = searchsorted(cumsum(closest as f64), u_t * float64(pot32), side='left'),
-// clipped to n - 1.  A thread owns a run of consecutive points; the 1024 run totals are scanned in LDS; a target lands in a run
-// by binary search and on a point by walking the run.  amb[0] counts the draws that fall within 4 float32 ulps of the potential
-// of a boundary of the cumulative sum: decisions that scikit-learn's own float32 potential (a BLAS sum) may take either way.
-__global__ __launch_bounds__(1024) void km_seed_draw_kernel(const float* __restrict__ closest, int64_t n, const float* __restrict__ pot32,
-                                                            const double* __restrict__ U, int64_t u_stride, int trials,
-                                                            int64_t* __restrict__ cand, unsigned int* __restrict__ amb) {
-  __shared__ double part[1024];
-  const int t = threadIdx.x;
-  const float* cl = closest + (int64_t)blockIdx.x * n;
-  const int64_t per = (n + 1023) / 1024, b = (int64_t)t * per;
+// One workgroup per restart, between two launches of the distance kernel.
+// (1) CHOICE among the `tprev` trials of the step that has just been computed: potential of a trial = float32 of the f64 sum of
+//     its tile partials; the first smallest wins (np.argmin over float32 potentials).  Its candidate becomes centre `step_prev` of
+//     the restart, its row of `rows` (index sel[g]) the restart's running closest-centre distances.
+// (2) DRAW of the next step's `trials` candidates (U != NULL): candidate = searchsorted(cumsum(closest as f64), u * float64(pot32),
+//     side='left'), clipped to n - 1.  The cumulative sum is never formed: the tile partials of the chosen row ARE its block sums —
+//     a thread owns a run of consecutive tiles, the 256 run totals are scanned in LDS, a target finds its run by binary search, its
+//     tile by walking the run's partials and its point by walking the tile's `pt` values.
+// amb[0] counts draws that land within 4 float32 ulps of the potential of a boundary of the cumulative sum, amb[1] choices whose
+// runner-up (a different point) is within 4 float32 ulps: decisions scikit-learn's own float32 BLAS sums may take either way.
+constexpr int KM_STEP_CACHE = 6144;      // tile partials (f64) of all trials of a restart kept in LDS when they fit (48 KiB)
+__global__ __launch_bounds__(256) void km_seed_step_kernel(const float* __restrict__ rows, const double* __restrict__ partial, int64_t ntile, int pt,
+                                                           int64_t n, int tprev, const int64_t* __restrict__ cand_prev, int64_t k, int64_t step_prev,
+                                                           const double* __restrict__ U, int64_t u_stride, int trials, float* __restrict__ pot32,
+                                                           int64_t* __restrict__ seeds, int* __restrict__ sel, int64_t* __restrict__ cand_next,
+                                                           unsigned int* __restrict__ amb) {
+  // What this kernel reads was written by the launch before it, mostly on other XCDs: every DEPENDENT global access is a
+  // round trip of 1 - 2 us.  So: one round for everything whose address is known at entry (all trials' tile partials into LDS,
+  // the uniforms, the candidates), the choice and the search out of LDS, one more round for the chosen tile's values.
+  __shared__ float pots[64];
+  __shared__ double runs[16][64];               // inclusive scan of the run totals, per trial (tprev <= 64: 16 at a time)
+  __shared__ double tp[KM_STEP_CACHE];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int64_t g = blockIdx.x;
+  const bool cached = (int64_t)tprev * ntile <= KM_STEP_CACHE && tprev <= 16;
+  const int64_t per = (ntile + 63) / 64, b = (int64_t)lane * per;
   int64_t e = b + per;
-  if (e > n) e = n;
-  double sum = 0.0;
-  for (int64_t j = b; j < e; ++j) sum += (double)cl[j];
-  part[t] = sum;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const double v = (t >= o) ? part[t - o] : 0.0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
+  if (e > ntile) e = ntile;
+  double u_mine = 0.0;
+  int64_t cand_mine = 0;
+  if (U && w == 0 && lane < trials) u_mine = U[g * u_stride + lane];
+  if (w == 0 && lane < tprev) cand_mine = cand_prev[g * tprev + lane];
+  for (int tr = w; tr < tprev; tr += 4) {       // wave w: trials w, w + 4, ...: lane l owns the run of tiles [l per, (l + 1) per)
+    const double* p = partial + (g * tprev + tr) * ntile;
+    double sum = 0.0;
+    for (int64_t j = b; j < e; ++j) {
+      const double v = p[j];
+      if (cached) tp[(int64_t)tr * ntile + j] = v;
+      sum += v;
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {           // inclusive scan over the lanes
+      const double v = __shfl_up(sum, o);
+      if (lane >= o) sum += v;
+    }
+    if (tr < 16) runs[tr][lane] = sum;
+    if (lane == 63) pots[tr] = (float)sum;
   }
-  if (t < trials) {
-    const double pot = (double)pot32[blockIdx.x];
-    const double target = U[(int64_t)blockIdx.x * u_stride + t] * pot;
-    int lo = 0, hi = 1023;                      // first run whose inclusive total reaches the target
+  __syncthreads();
+  if (w != 0) return;
+  int bsel = 0;
+  for (int tr = 1; tr < tprev; ++tr)
+    if (pots[tr] < pots[bsel]) bsel = tr;
+  const int64_t cand_best = __shfl(cand_mine, bsel);
+  {
+    const bool close = lane < tprev && lane != bsel && cand_mine != cand_best && pots[lane] - pots[bsel] <= 4.f * 1.1920928955078125e-07f * pots[bsel];
+    const unsigned long long any = __ballot(close);
+    if (lane == 0) {
+      if (any) atomicAdd(amb + 1, 1u);
+      seeds[g * k + step_prev] = cand_best;
+      pot32[g] = pots[bsel];
+      sel[g] = (int)(g * tprev + bsel);
+    }
+  }
+  if (!U) return;
+  // the draw: candidate = searchsorted(cumsum(chosen row), u * float64(pot32), 'left') through run totals -> tile partials -> values
+  const int64_t row = g * tprev + bsel;
+  const double* bp = partial + row * ntile;
+  const float* cl = rows + row * n;
+  if (bsel >= 16) {                              // (never with scikit-learn's 2 + log k trials) scan the chosen row again
+    double sum = 0.0;
+    for (int64_t j = b; j < e; ++j) sum += bp[j];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double v = __shfl_up(sum, o);
+      if (lane >= o) sum += v;
+    }
+    runs[0][lane] = sum;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+  const double* rn = runs[bsel < 16 ? bsel : 0];
+  if (lane < trials) {
+    const double pot = (double)pots[bsel];
+    const double target = u_mine * pot;
+    int lo = 0, hi = 63;                        // first run whose inclusive total reaches the target
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
-      if (part[mid] >= target) hi = mid; else lo = mid + 1;
+      if (rn[mid] >= target) hi = mid; else lo = mid + 1;
     }
-    double run = lo ? part[lo - 1] : 0.0;
-    int64_t j = (int64_t)lo * per, last = j + per;
-    if (last > n) last = n;
+    const bool beyond = !(rn[63] >= target);    // the target lies above the whole sum (float32 rounding of the potential): n - 1
+    double run = lo ? rn[lo - 1] : 0.0;
+    int64_t tile = (int64_t)lo * per, tlast = tile + per;
+    if (tlast > ntile) tlast = ntile;
+    for (; tile < tlast - 1; ++tile) {           // the tile inside the run
+      const double nx = run + (cached ? tp[(int64_t)bsel * ntile + tile] : bp[tile]);
+      if (nx >= target) break;
+      run = nx;
+    }
+    if (tile > ntile - 1) tile = ntile - 1;
     int64_t pick = n - 1;
     double below = run, at = run;
-    for (; j < last; ++j) {
-      below = run;
-      run += (double)cl[j];
-      at = run;
-      if (run >= target) { pick = j; break; }
+    if (!beyond) {
+      // the tile's values first (all loads in flight), then the walk
+      const int64_t j0 = tile * pt;
+      float v[64];
+#pragma unroll
+      for (int u = 0; u < 64; ++u) v[u] = (u < pt && j0 + u < n) ? cl[j0 + u] : 0.f;
+      bool found = false;
+#pragma unroll
+      for (int u = 0; u < 64; ++u) {
+        if (!found && u < pt && j0 + u < n) {
+          below = run;
+          run += (double)v[u];
+          at = run;
+          if (run >= target) { pick = j0 + u; found = true; }
+        }
+      }
+      if (!found) {                              // rounding between the partial and the element sums: continue into the following tiles
+        for (int64_t j = j0 + pt; j < n; ++j) {
+          below = run;
+          run += (double)cl[j];
+          at = run;
+          if (run >= target) { pick = j; break; }
+        }
+      }
     }
-    if (pick > n - 1) pick = n - 1;
-    if (pick < 0) pick = 0;
     const double band = 4.0 * 1.1920928955078125e-07 * pot;
     if (target - below <= band || at - target <= band) atomicAdd(amb, 1u);
-    cand[(int64_t)blockIdx.x * trials + t] = pick;
-  }
-}
-
-// One restart per blockIdx.x (the row copy shared by gridDim.y workgroups): potential of every trial = float32 of the f64 sum
-// of its tile partials; the first smallest wins (np.argmin over float32 potentials); its row becomes the restart's closest-centre
-// distances.  rows == closest (the first centre): nothing to copy.
-__global__ __launch_bounds__(256) void km_seed_choose_kernel(const float* __restrict__ rows, const double* __restrict__ partial, int64_t ntile,
-                                                             int64_t n, int trials, const int64_t* __restrict__ cand,
-                                                             float* __restrict__ closest, float* __restrict__ pot32,
-                                                             int64_t* __restrict__ seeds, int64_t k, int64_t step, unsigned int* __restrict__ amb) {
-  __shared__ double red[256];
-  __shared__ float pots[64];
-  __shared__ int best_s;
-  const int t = threadIdx.x;
-  const int64_t i = blockIdx.x;
-  for (int tr = 0; tr < trials; ++tr) {
-    const double* p = partial + (i * trials + tr) * ntile;
-    double sum = 0.0;
-    for (int64_t q = t; q < ntile; q += 256) sum += p[q];
-    red[t] = sum;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (t < o) red[t] += red[t + o];
-      __syncthreads();
-    }
-    if (t == 0) pots[tr] = (float)red[0];
-    __syncthreads();
-  }
-  if (t == 0) {
-    int bsel = 0;
-    for (int tr = 1; tr < trials; ++tr)
-      if (pots[tr] < pots[bsel]) bsel = tr;
-    best_s = bsel;
-    if (blockIdx.y == 0) {     // another candidate within 4 float32 ulps of the winner: scikit-learn's BLAS sums may order them either way
-      bool close = false;
-      for (int tr = 0; tr < trials; ++tr)
-        if (tr != bsel && cand[i * trials + tr] != cand[i * trials + bsel] && pots[tr] - pots[bsel] <= 4.f * 1.1920928955078125e-07f * pots[bsel]) close = true;
-      if (close) atomicAdd(amb + 1, 1u);
-    }
-  }
-  __syncthreads();
-  const int bs = best_s;
-  const float* src = rows + (i * trials + bs) * n;
-  float* dst = closest + i * n;
-  if (src != dst)
-    for (int64_t j = (int64_t)blockIdx.y * 256 + t; j < n; j += (int64_t)gridDim.y * 256) dst[j] = src[j];
-  if (t == 0 && blockIdx.y == 0) {
-    seeds[i * k + step] = cand[i * trials + bs];
-    pot32[i] = pots[bs];
+    cand_next[g * trials + lane] = pick;
   }
 }
 
@@ -539,13 +607,12 @@ __global__ __launch_bounds__(256) void km_update_kernel(const float* __restrict_
   }
 }
 
-// One thread per restart, after the E (+ M) step of Lloyd iteration `it`: scikit-learn's convergence logic
+// One wave per restart, after the E (+ M) step of Lloyd iteration `it`: scikit-learn's convergence logic
 // (_kmeans_single_lloyd): swap the centre buffers; unchanged labels -> done, no further E step; shift <= tol or the last
 // iteration -> one more E step with the new centres.  A restart with empty clusters waits for the host (KM_RELOC).
-__global__ void km_state_kernel(KmState* __restrict__ st, int n_init, int64_t k, int64_t strips, const double* __restrict__ shift_part,
-                                const double* __restrict__ tol_abs, int it, int max_iter, int only, int* __restrict__ status) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n_init) return;
+__global__ __launch_bounds__(64) void km_state_kernel(KmState* __restrict__ st, int n_init, int64_t k, int64_t strips, const double* __restrict__ shift_part,
+                                                      const double* __restrict__ tol_abs, int it, int max_iter, int only, int* __restrict__ status) {
+  const int g = blockIdx.x, lane = threadIdx.x;
   if (only < 0 || only == g) {
     KmState s = st[g];
     if (s.state == KM_FINAL) {
@@ -555,7 +622,8 @@ __global__ void km_state_kernel(KmState* __restrict__ st, int n_init, int64_t k,
         s.state = KM_RELOC;
       } else {
         double sh = 0.0;
-        for (int64_t q = 0; q < k * strips; ++q) sh += shift_part[(int64_t)g * k * strips + q];
+        for (int64_t q = lane; q < k * strips; q += 64) sh += shift_part[(int64_t)g * k * strips + q];
+        sh = wave_sum(sh);
         s.shift = sh;
         s.cur ^= 1;
         s.n_iter = it + 1;
@@ -566,9 +634,11 @@ __global__ void km_state_kernel(KmState* __restrict__ st, int n_init, int64_t k,
         s.changed = 0;
       }
     }
-    st[g] = s;
+    if (lane == 0) st[g] = s;
+    if (lane == 0) status[g] = s.state;
+  } else if (lane == 0) {
+    status[g] = st[g].state;
   }
-  status[g] = st[g].state;
 }
 
 // Relocation of empty clusters (scikit-learn's _relocate_empty_clusters_dense), one workgroup per restart that needs it:
@@ -758,10 +828,9 @@ size_t kmeans_scratch_bytes(int64_t n, int64_t d, int64_t k, int64_t n_init, int
   b += al((size_t)nblk * d * 8);               // column partials
   b += 3 * al((size_t)d * 8) + al((size_t)d * 4);   // mean64, var64, (spare), mean32
   b += al(256);                                // tol_abs, best, amb
-  b += al((size_t)R * n * 4);                  // trial rows
-  b += al((size_t)n_init * n * 4);             // closest
-  b += al((size_t)R * ntile * 8);              // row partials
-  b += al((size_t)R * 8) + al((size_t)n_init * 8) + al((size_t)n_init * 4);   // cand, first, pot32
+  b += 2 * al((size_t)R * n * 4);              // trial rows, two steps
+  b += 2 * al((size_t)R * 2 * ntile * 8);      // their tile partials (32-point tiles at most)
+  b += 2 * al((size_t)R * 8) + al((size_t)n_init * 8) + al((size_t)n_init * 4) + al((size_t)n_init * 4);   // cand x 2, first, pot32, sel
   b += al((size_t)n_init * (k > 1 ? k - 1 : 1) * trials * 8);                 // uniforms
   b += al((size_t)S * 8);                      // seeds
   b += 2 * al((size_t)S * ds * 4);             // centres x 2
@@ -796,12 +865,15 @@ int launch_kmeans_fit(const float* X, int64_t n, int64_t d, int64_t k, int64_t n
   double* tol_abs = (double*)misc;
   int* best = (int*)(misc + 8);
   unsigned int* amb = (unsigned int*)(misc + 16);
-  float* rows = (float*)take((size_t)R * n * 4);
-  float* closest = (float*)take((size_t)n_init * n * 4);
-  double* rpart = (double*)take((size_t)R * ntile * 8);
-  int64_t* cand = (int64_t*)take((size_t)R * 8);
+  float* rows[2];
+  double* rpart[2];
+  int64_t* cand[2];
+  for (int u = 0; u < 2; ++u) rows[u] = (float*)take((size_t)R * n * 4);
+  for (int u = 0; u < 2; ++u) rpart[u] = (double*)take((size_t)R * 2 * ntile * 8);
+  for (int u = 0; u < 2; ++u) cand[u] = (int64_t*)take((size_t)R * 8);
   int64_t* first = (int64_t*)take((size_t)n_init * 8);
   float* pot32 = (float*)take((size_t)n_init * 4);
+  int* sel = (int*)take((size_t)n_init * 4);
   const size_t u_count = (size_t)n_init * (k > 1 ? k - 1 : 1) * trials;
   double* U = (double*)take(u_count * 8);
   int64_t* seeds = (int64_t*)take((size_t)S * 8);
@@ -824,7 +896,8 @@ int launch_kmeans_fit(const float* X, int64_t n, int64_t d, int64_t k, int64_t n
   int* map = (int*)take((size_t)k * 4);
 
   const size_t lds = (size_t)4 * KM_T * KM_LD * 8;
-  MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(km_seed_dots_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(km_seed_dots_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(km_seed_dots_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(km_assign_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
   // the caller's stream of random numbers
@@ -838,7 +911,7 @@ int launch_kmeans_fit(const float* X, int64_t n, int64_t d, int64_t k, int64_t n
   MMF_LAUNCH_CHECK();
   hipLaunchKernelGGL(km_colfin_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, s, colpart, nblk, n, d, mean64, (float*)nullptr);
   MMF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(km_colmean_seq_kernel, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, s, X, n, d, mean32);
+  hipLaunchKernelGGL(km_colmean_seq_kernel, dim3((unsigned)((d + CM_COLS - 1) / CM_COLS)), dim3(256), 0, s, X, n, d, mean32);
   MMF_LAUNCH_CHECK();
   hipLaunchKernelGGL(km_colsum_kernel, cgrid, dim3(256), 0, s, X, n, d, (const double*)mean64, colpart);
   MMF_LAUNCH_CHECK();
@@ -849,28 +922,31 @@ int launch_kmeans_fit(const float* X, int64_t n, int64_t d, int64_t k, int64_t n
   hipLaunchKernelGGL(km_centre_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, X, n, d, ds, mean32, Xc, xx);
   MMF_LAUNCH_CHECK();
 
-  // k-means++ for all restarts in lockstep
-  hipLaunchKernelGGL(km_seed_first_kernel, dim3((unsigned)((n_init + 63) / 64)), dim3(64), 0, s, first, n_init, k, seeds, cand);
+  // k-means++ for all restarts in lockstep: per step one small launch (choice of the previous step's trials + draw of the next
+  // candidates) and one launch of the distance kernel; the running closest-centre distances are a row of the previous step's output
+  hipLaunchKernelGGL(km_seed_first_kernel, dim3((unsigned)((n_init + 63) / 64)), dim3(64), 0, s, first, n_init, k, seeds, cand[0]);
   MMF_LAUNCH_CHECK();
-  unsigned choose_split = (unsigned)((n + 2047) / 2048);
-  if (choose_split > 32) choose_split = 32;
-  if (choose_split < 1) choose_split = 1;
-  hipLaunchKernelGGL(km_seed_dots_kernel, dim3((unsigned)ntile, (unsigned)((n_init + KM_T - 1) / KM_T)), dim3(256), lds, s, Xc, n, ds, xx, cand, n_init,
-                     (int64_t)1, (const float*)nullptr, closest, rpart);
+  const bool small_tiles = ntile < 512;          // 64-point tiles would not give every SIMD two waves: 32-point tiles
+  const int pt = small_tiles ? 32 : 64;
+  const int64_t stile = (n + pt - 1) / pt;
+  auto dots = [&](const int64_t* cd, int64_t Rn, int64_t group, const float* prev, float* out, double* part) {
+    const dim3 grid((unsigned)stile, (unsigned)((Rn + KM_T - 1) / KM_T));
+    if (small_tiles) hipLaunchKernelGGL(km_seed_dots_kernel<2>, grid, dim3(256), lds, s, Xc, n, ds, xx, cd, Rn, group, prev, sel, out, part);
+    else hipLaunchKernelGGL(km_seed_dots_kernel<4>, grid, dim3(256), lds, s, Xc, n, ds, xx, cd, Rn, group, prev, sel, out, part);
+  };
+  dots(cand[0], n_init, 1, nullptr, rows[0], rpart[0]);
   MMF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(km_seed_choose_kernel, dim3((unsigned)n_init, 1), dim3(256), 0, s, closest, rpart, ntile, n, 1, cand, closest, pot32, seeds, k,
-                     (int64_t)0, amb);
-  MMF_LAUNCH_CHECK();
-  for (int64_t step = 1; step < k; ++step) {
-    hipLaunchKernelGGL(km_seed_draw_kernel, dim3((unsigned)n_init), dim3(1024), 0, s, closest, n, pot32, U + (step - 1) * trials, (k - 1) * trials, trials,
-                       cand, amb);
+  int cur = 0, tprev = 1;
+  for (int64_t step = 1; step <= k; ++step) {
+    const bool last = step == k;
+    hipLaunchKernelGGL(km_seed_step_kernel, dim3((unsigned)n_init), dim3(256), 0, s, rows[cur], rpart[cur], stile, pt, n, tprev, cand[cur], k, step - 1,
+                       last ? (const double*)nullptr : U + (step - 1) * trials, (k - 1) * trials, trials, pot32, seeds, sel, cand[cur ^ 1], amb);
     MMF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(km_seed_dots_kernel, dim3((unsigned)ntile, (unsigned)((R + KM_T - 1) / KM_T)), dim3(256), lds, s, Xc, n, ds, xx, cand, R,
-                       (int64_t)trials, closest, rows, rpart);
+    if (last) break;
+    dots(cand[cur ^ 1], R, trials, rows[cur], rows[cur ^ 1], rpart[cur ^ 1]);
     MMF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(km_seed_choose_kernel, dim3((unsigned)n_init, choose_split), dim3(256), 0, s, rows, rpart, ntile, n, trials, cand, closest, pot32,
-                       seeds, k, step, amb);
-    MMF_LAUNCH_CHECK();
+    cur ^= 1;
+    tprev = trials;
   }
   if (out_seeds) MMF_HIP(hipMemcpyAsync(out_seeds, seeds, (size_t)S * 8, hipMemcpyDeviceToDevice, s));
 
@@ -896,7 +972,7 @@ int launch_kmeans_fit(const float* X, int64_t n, int64_t d, int64_t k, int64_t n
                          shift_part);
       MMF_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(km_state_kernel, dim3((unsigned)((n_init + 63) / 64)), dim3(64), 0, s, st, (int)n_init, k, strips, shift_part, tol_abs, it, max_iter,
+    hipLaunchKernelGGL(km_state_kernel, dim3((unsigned)n_init), dim3(64), 0, s, st, (int)n_init, k, strips, shift_part, tol_abs, it, max_iter,
                        -1, status);
     MMF_LAUNCH_CHECK();
     MMF_HIP(hipMemcpyAsync(h_status.data(), status, (size_t)n_init * 4, hipMemcpyDeviceToHost, s));
@@ -906,7 +982,7 @@ int launch_kmeans_fit(const float* X, int64_t n, int64_t d, int64_t k, int64_t n
       hipLaunchKernelGGL(km_relocate_kernel, dim3(1), dim3(1024), 0, s, Xc, n, ds, k, (int)g, labels, offsets, C0, C1, sums32, st, dist, cntf, shift_part,
                          strips);
       MMF_LAUNCH_CHECK();
-      hipLaunchKernelGGL(km_state_kernel, dim3((unsigned)((n_init + 63) / 64)), dim3(64), 0, s, st, (int)n_init, k, strips, shift_part, tol_abs, it, max_iter,
+      hipLaunchKernelGGL(km_state_kernel, dim3((unsigned)n_init), dim3(64), 0, s, st, (int)n_init, k, strips, shift_part, tol_abs, it, max_iter,
                          (int)g, status);
       MMF_LAUNCH_CHECK();
       MMF_HIP(hipMemcpyAsync(h_status.data(), status, (size_t)n_init * 4, hipMemcpyDeviceToHost, s));

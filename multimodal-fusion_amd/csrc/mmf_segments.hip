@@ -366,133 +366,6 @@ int launch_knn_pairs(const int64_t* nbr, int64_t n, int k, const int64_t* labels
   return MMF_OK;
 }
 
-// ---- k-means++ seeding ---------------------------------------------------------------------------------------------
-// The distance rows — out[r][i] = min(closest[r / group][i], |x_i - c_r|^2) with per-tile partial row sums — come from the
-// register-tiled direct-difference kernel of mmf_direct.hip (launch_seed_dists_tiled: 8 x 8 outputs per lane, 0.65 of
-// the vector-ALU roof).  The first version here — candidate rows in LDS, lanes across k, a butterfly per point — reached
-// a tenth of that roof and was 15 of the 25 ms of a fit at N = 16384.
-// One workgroup per seeding: draw `trials` candidates with probability proportional to the running closest-centre
-// distance (inverse-CDF sampling: a thread owns a run of consecutive points, the 1024 run totals are scanned in LDS, a
-// uniform lands in a run by binary search and at a point by walking the run).  f64 sums, fixed order: deterministic.
-__global__ __launch_bounds__(1024) void seed_draw_kernel(const float* __restrict__ closest, int64_t n, const float* __restrict__ U,
-                                                         int trials, int64_t* __restrict__ cand) {
-  __shared__ double part[1024];
-  const int t = threadIdx.x;
-  const float* cl = closest + (int64_t)blockIdx.x * n;
-  const int64_t per = (n + 1023) / 1024, b = (int64_t)t * per;
-  int64_t e = b + per;
-  if (e > n) e = n;
-  double sum = 0.0;
-  for (int64_t j = b; j < e; ++j) sum += (double)cl[j];
-  part[t] = sum;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const double v = (t >= o) ? part[t - o] : 0.0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  if (t < trials) {
-    const double target = (double)U[(int64_t)blockIdx.x * trials + t] * part[1023];
-    int lo = 0, hi = 1023;                      // first run whose inclusive total reaches the target
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (part[mid] >= target) hi = mid; else lo = mid + 1;
-    }
-    double run = lo ? part[lo - 1] : 0.0;
-    int64_t j = (int64_t)lo * per, last = j + per;
-    if (last > n) last = n;
-    int64_t pick = (last > 0) ? last - 1 : 0;
-    for (; j < last; ++j) {
-      run += (double)cl[j];
-      if (run >= target) { pick = j; break; }
-    }
-    if (pick > n - 1) pick = n - 1;
-    cand[(int64_t)blockIdx.x * trials + t] = pick;
-  }
-}
-
-// One workgroup per seeding: the trial with the smallest potential becomes the next centre; its clamped distance row
-// becomes the seeding's running closest-centre distance.
-__global__ __launch_bounds__(256) void seed_choose_kernel(const float* __restrict__ dc, const double* __restrict__ partial, int64_t nblk,
-                                                          int64_t n, int trials, const int64_t* __restrict__ cand,
-                                                          float* __restrict__ closest, int64_t* __restrict__ cidx, int64_t k, int64_t step) {
-  __shared__ double red[256];
-  __shared__ int best_s;
-  __shared__ double best_pot;
-  const int t = threadIdx.x;
-  const int64_t i = blockIdx.x;
-  for (int tr = 0; tr < trials; ++tr) {
-    const double* p = partial + (i * trials + tr) * nblk;
-    double sum = 0.0;
-    for (int64_t q = t; q < nblk; q += 256) sum += p[q];
-    red[t] = sum;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (t < o) red[t] += red[t + o];
-      __syncthreads();
-    }
-    if (t == 0 && (tr == 0 || red[0] < best_pot)) { best_pot = red[0]; best_s = tr; }
-    __syncthreads();
-  }
-  const int bs = best_s;
-  const float* src = dc + (i * trials + bs) * n;
-  float* dst = closest + i * n;
-  // the row copy is shared by the gridDim.y workgroups of this seeding (each finds the same best trial for itself)
-  for (int64_t j = (int64_t)blockIdx.y * 256 + t; j < n; j += (int64_t)gridDim.y * 256) dst[j] = src[j];
-  if (t == 0 && blockIdx.y == 0) cidx[i * k + step] = cand[i * trials + bs];
-}
-
-// first centre of every seeding: a uniform index
-__global__ void seed_first_kernel(const float* __restrict__ U0, int64_t n, int64_t n_init, int64_t k, int64_t* __restrict__ cidx,
-                                  int64_t* __restrict__ cand) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_init) return;
-  int64_t j = (int64_t)((double)U0[i] * (double)n);
-  if (j > n - 1) j = n - 1;
-  if (j < 0) j = 0;
-  cidx[i * k] = j;
-  cand[i] = j;
-}
-
-int seed_distances_max_dim() { return 1 << 20; }
-int launch_seed_distances(const float* X, int64_t n, int64_t d, const int64_t* cand, const float* cand_rows, int64_t n_cand,
-                          int64_t group, const float* closest, float* out, hipStream_t s) {
-  return launch_seed_dists_tiled(X, n, d, cand, cand_rows, n_cand, group, closest, out, nullptr, s);
-}
-
-// k-means++ for n_init seedings in lockstep, all k - 1 steps enqueued by this one call (three launches per step).
-// U0 [n_init], U [k - 1][n_init][trials]: uniforms in [0, 1).  scratch: kmeanspp_scratch_bytes.
-size_t kmeanspp_scratch_bytes(int64_t n, int64_t n_init, int trials) {
-  const size_t R = (size_t)n_init * trials, nblk = (size_t)seed_tiles(n, (int64_t)n_init * trials);
-  return ((R * n * 4 + 255) & ~size_t(255)) + (((size_t)n_init * n * 4 + 255) & ~size_t(255)) + ((R * nblk * 8 + 255) & ~size_t(255)) +
-         ((R * 8 + 255) & ~size_t(255)) + 256;
-}
-int launch_kmeanspp(const float* X, int64_t n, int64_t d, int64_t k, int64_t n_init, int trials, const float* U0, const float* U,
-                    int64_t* cidx, void* scratch, hipStream_t s) {
-  const size_t R = (size_t)n_init * trials, nblk = (size_t)seed_tiles(n, (int64_t)n_init * trials);
-  char* p = static_cast<char*>(scratch);
-  float* dc = reinterpret_cast<float*>(p); p += (R * n * 4 + 255) & ~size_t(255);
-  float* closest = reinterpret_cast<float*>(p); p += ((size_t)n_init * n * 4 + 255) & ~size_t(255);
-  double* partial = reinterpret_cast<double*>(p); p += (R * nblk * 8 + 255) & ~size_t(255);
-  int64_t* cand = reinterpret_cast<int64_t*>(p);
-  hipLaunchKernelGGL(seed_first_kernel, dim3((unsigned)((n_init + 63) / 64)), dim3(64), 0, s, U0, n, n_init, k, cidx, cand);
-  MMF_LAUNCH_CHECK();
-  MMF_TRY(launch_seed_dists_tiled(X, n, d, cand, nullptr, n_init, 1, nullptr, closest, nullptr, s));
-  unsigned choose_split = (unsigned)((n + 2047) / 2048);      // workgroups per seeding that share the row copy of the choice
-  if (choose_split > 32) choose_split = 32;
-  if (choose_split < 1) choose_split = 1;
-  for (int64_t step = 1; step < k; ++step) {
-    hipLaunchKernelGGL(seed_draw_kernel, dim3((unsigned)n_init), dim3(1024), 0, s, closest, n, U + (step - 1) * n_init * trials, trials, cand);
-    MMF_LAUNCH_CHECK();
-    MMF_TRY(launch_seed_dists_tiled(X, n, d, cand, nullptr, (int64_t)R, trials, closest, dc, partial, s));
-    hipLaunchKernelGGL(seed_choose_kernel, dim3((unsigned)n_init, choose_split), dim3(256), 0, s, dc, partial, (int64_t)nblk, n, trials, cand, closest,
-                       cidx, k, step);
-    MMF_LAUNCH_CHECK();
-  }
-  return MMF_OK;
-}
-
 int segment_max_segments() { return SEG_MAX; }
 
 }  // namespace mmf

@@ -442,50 +442,6 @@ def knn_pairs(nbr: torch.Tensor, labels: Optional[torch.Tensor] = None) -> Tuple
     return lo[:E], hi[:E]
 
 
-def seed_distances(X: torch.Tensor, cand: torch.Tensor, group: int = 1, closest: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[r, i] = min(closest[r // group, i], |x_i - c_r|^2) (mmf_seed_distances).  X f32 [n, d].  cand: int64 [R] row
-    indices into X (k-means++ seeding: the trial candidates of several independent seedings side by side) or a float
-    [R, d] matrix of explicit rows (the centroids of all restarts: the assignment step).  Returns f32 [R, n]."""
-    X = _feat(X, "seed_distances X").float()
-    _need_gpu(X, "seed_distances")
-    n = X.shape[0]
-    if cand.is_floating_point():
-        rows = _feat(cand.to(X.device), "seed_distances candidate rows").float()
-        if rows.shape[1] != X.shape[1]:
-            raise ValueError("seed_distances: candidate rows must have X's feature dimension")
-        idx, R = None, rows.shape[0]
-    else:
-        idx, rows = cand.to(device=X.device, dtype=torch.int64).contiguous(), None
-        R = idx.numel()
-    if closest is not None:
-        closest = closest.to(device=X.device, dtype=torch.float32).contiguous()
-        if closest.shape != (-(-R // int(group)), n):
-            raise ValueError("seed_distances: closest must be [ceil(R / group), n]")
-    out = torch.empty((R, n), dtype=torch.float32, device=X.device)
-    rc = _lib.lib().mmf_seed_distances(_p(X), n, X.shape[1], _p(idx), _p(rows), R, int(group), _p(closest), _p(out),
-                                       X.device.index or 0, _stream(X.device))
-    _lib.check(rc, "mmf_seed_distances")
-    return out
-
-
-def kmeanspp_seed(X: torch.Tensor, k: int, u_first: torch.Tensor, u_steps: torch.Tensor) -> torch.Tensor:
-    """Initial centres of n_init k-means++ seedings in lockstep (mmf_kmeanspp_seed): u_first [n_init] and
-    u_steps [k - 1, n_init, trials] are the caller's uniforms in [0, 1).  Returns int64 [n_init, k] row indices of X."""
-    X = _feat(X, "kmeanspp_seed X").float()
-    _need_gpu(X, "kmeanspp_seed")
-    n_init = u_first.numel()
-    u_first = u_first.to(device=X.device, dtype=torch.float32).contiguous()
-    u_steps = u_steps.to(device=X.device, dtype=torch.float32).contiguous()
-    if k > 1 and (u_steps.dim() != 3 or u_steps.shape[0] != k - 1 or u_steps.shape[1] != n_init):
-        raise ValueError("kmeanspp_seed: u_steps must be [k - 1, n_init, trials]")
-    trials = int(u_steps.shape[2]) if k > 1 else 1
-    out = torch.empty((n_init, int(k)), dtype=torch.int64, device=X.device)
-    rc = _lib.lib().mmf_kmeanspp_seed(_p(X), X.shape[0], X.shape[1], int(k), n_init, trials, _p(u_first), _p(u_steps), _p(out),
-                                      X.device.index or 0, _stream(X.device))
-    _lib.check(rc, "mmf_kmeanspp_seed")
-    return out
-
-
 def kmeans_fit(X: torch.Tensor, n_clusters: int, first_centres, uniforms, *, max_iter: int = 300, tol: float = 1e-4,
                return_seeds: bool = False):
     """scikit-learn's KMeans fit on the device, decision for decision (mmf_kmeans_fit).  X f32 [n, d] on the GPU;
