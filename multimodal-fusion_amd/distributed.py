@@ -130,12 +130,16 @@ def _buffer(key, shape, dtype, device):
     return buf
 
 
-def _pick_chunks(rows: int, world: int, chunks: Optional[int]) -> int:
-    """Pieces the operand exchange is cut into (each piece: one all-gather + one scan launch)."""
+def _pick_chunks(rows: int, world: int, chunks: Optional[int], own_first: bool = False) -> int:
+    """Pieces the operand exchange is cut into (each piece: one all-gather + the scan launches behind it).  With the
+    rank's own rows scanned first the whole exchange travels under that scan, so one piece is the default; without,
+    the first piece is exposed and the exchange is cut in up to four."""
     if chunks is not None:
         if chunks < 1 or rows % chunks:
             raise ValueError(f"chunks={chunks} must divide the {rows} rows of a shard")
         return chunks
+    if own_first:
+        return 1
     for s in (4, 2):
         if rows % s == 0 and (rows // s) * world >= 16384:
             return s
@@ -143,17 +147,26 @@ def _pick_chunks(rows: int, world: int, chunks: Optional[int]) -> int:
 
 
 def _overlapped_simtopk(x_local, n_total, lo, hi, world, *, metric, lam, k, exclude_self, operand, group, return_stats,
-                        chunks=None, col_splits=0):
-    """Pipelined phase path.  Each rank prepares the 16-bit operands of its own rows; the ranks
-    exchange them in S chunks (chunk c = rows [c*rows/S, (c+1)*rows/S) of every rank), and the scan of chunk c —
-    one launch of mmf_simtopk_panels — runs while chunk c+1 is on the wire.  The f32 all-gather, needed only by
-    the exact re-rank, is issued last and is waited for between the last scan launch and the re-rank.
-    Exposed communication: one small gather (5 floats per row) and the first chunk."""
+                        chunks=None, col_splits=0, own_first=None):
+    """Pipelined phase path.  Each rank prepares the 16-bit operands of its own rows and the ranks
+    exchange them in S chunks (chunk c = rows [c*rows/S, (c+1)*rows/S) of every rank) by asynchronous all-gathers.
+
+    own_first (default for world > 1; SURVEY.md §8(e) "scan the local shard first"): the first scan launch takes the
+    rank's OWN rows as its columns — they are local, nothing is waited for — and every gathered chunk is scanned as the
+    two column ranges either side of the rank's own segment (ranks below it, ranks above it), each behind the chunk's
+    arrival event.  The whole exchange travels under the scan of the own rows.
+    own_first=False: every column is scanned out of the gathered chunks (S launches, the first chunk exposed).
+
+    The f32 all-gather, needed only by the exact re-rank, is issued last and is waited for between the last scan launch
+    and the re-rank."""
     from . import ops
     dev = x_local.device
     rows, d = x_local.shape
     dp = ops.padded_dim(d)
-    S = _pick_chunks(rows, world, chunks)
+    me = dist.get_rank(group)
+    if own_first is None:
+        own_first = world > 1
+    S = _pick_chunks(rows, world, chunks, own_first)
     seg = rows // S
     rows_pad = (rows + 255) // 256 * 256
     z16 = torch.float16 if operand == "f16" else torch.bfloat16
@@ -165,9 +178,9 @@ def _overlapped_simtopk(x_local, n_total, lo, hi, world, *, metric, lam, k, excl
     ops.row_scalars(x_local, metric, pack_l[0], maxn)
     if metric != "cosine":
         _allreduce_max(maxn, group)                      # the common power-of-two scale needs the global maximum
-    z_l = _buffer("z_l", (rows_pad, dp), z16, dev)
-    if rows_pad != rows:
-        z_l[rows:].zero_()
+    z_buf = _buffer("z_l", (rows_pad + 256, dp), z16, dev)                        # + the slack a scan panel needs behind it
+    z_buf[rows:].zero_()
+    z_l = z_buf[:rows_pad]
     send = _buffer("send", (5 * rows + 4,), torch.float32, dev)                   # per-row scalars + this shard's maxima
     max4 = send[5 * rows:]
     max4.zero_()
@@ -178,10 +191,8 @@ def _overlapped_simtopk(x_local, n_total, lo, hi, world, *, metric, lam, k, excl
     _gather_into(recv, send, group)
     m_c = world * seg
     m_pad = (m_c + 255) // 256 * 256
-    zc = _buffer("zc", (S, m_pad + 256, dp), z16, dev)
+    zc = _buffer("zc", (S, m_pad + 512, dp), z16, dev)
     zc[:, m_c:].zero_()                                  # padding rows (never touched by the gathers): zero operands ...
-    cb = _buffer("cb", (S, m_pad + 256), torch.float32, dev)
-    cb[:, m_c:].fill_(float("-inf"))                     # ... and -inf biases, the scan's only column mask
     side_stream = _BUFFERS.get(("side_stream", dev))
     if side_stream is None:
         side_stream = _BUFFERS[("side_stream", dev)] = torch.cuda.Stream(device=dev)
@@ -192,21 +203,54 @@ def _overlapped_simtopk(x_local, n_total, lo, hi, world, *, metric, lam, k, excl
     max_all = recv[:, 5 * rows:].max(dim=0).values.contiguous()
     per_row = recv[:, :5 * rows].view(world, 5, rows)
     c_scal = per_row[:, 0].reshape(n_total)
-    cb[:, :m_c] = per_row[:, 4].reshape(world, S, seg).permute(1, 0, 2).reshape(S, m_c)
-    panels = [dict(Z=zc[c], cb=cb[c], m=m_c, m_pad=m_pad, seg_len=seg, seg_stride=rows, id_base=c * seg, event=events[c])
-              for c in range(S)]
+    bias = per_row[:, 4].reshape(world, S, seg)          # [rank, chunk, row of the chunk]
+    ninf = float("-inf")
+    panels = []
+    if own_first:
+        cb_own = _buffer("cb_own", (rows_pad + 256,), torch.float32, dev)
+        cb_own[rows:].fill_(ninf)                        # ... and -inf biases, the scan's only column mask
+        cb_own[:rows].copy_(pack_l[4, :rows])
+        panels.append(dict(Z=z_buf, cb=cb_own, m=rows, m_pad=rows_pad, seg_len=0, seg_stride=0, id_base=me * rows, event=None))
+        below, above = me * seg, (world - 1 - me) * seg  # columns of a gathered chunk either side of the own segment
+        cb_lo = _buffer("cb_lo", (S, m_pad + 256), torch.float32, dev)
+        cb_hi = _buffer("cb_hi", (S, m_pad + 256), torch.float32, dev)
+        if below:
+            cb_lo[:, below:].fill_(ninf)
+            cb_lo[:, :below] = bias[:me].permute(1, 0, 2).reshape(S, below)
+        if above:
+            cb_hi[:, above:].fill_(ninf)
+            cb_hi[:, :above] = bias[me + 1:].permute(1, 0, 2).reshape(S, above)
+        for c in range(S):
+            if below:
+                panels.append(dict(Z=zc[c], cb=cb_lo[c], m=below, m_pad=(below + 255) // 256 * 256, seg_len=seg, seg_stride=rows,
+                                   id_base=c * seg, event=events[c]))
+            if above:
+                panels.append(dict(Z=zc[c, (me + 1) * seg:], cb=cb_hi[c], m=above, m_pad=(above + 255) // 256 * 256, seg_len=seg,
+                                   seg_stride=rows, id_base=(me + 1) * rows + c * seg, event=events[c]))
+    else:
+        cb = _buffer("cb", (S, m_pad + 256), torch.float32, dev)
+        cb[:, m_c:].fill_(ninf)
+        cb[:, :m_c] = bias.permute(1, 0, 2).reshape(S, m_c)
+        panels = [dict(Z=zc[c], cb=cb[c], m=m_c, m_pad=m_pad, seg_len=seg, seg_stride=rows, id_base=c * seg, event=events[c])
+                  for c in range(S)]
     q = dict(Z=z_l, scal=pack_l[0], zn=pack_l[1], rn=pack_l[2], un=pack_l[3], cb=pack_l[4])
-    return ops.simtopk_panels(x_local, full, q, c_scal, panels, max_all, operand=operand, metric=metric, lam=lam, k=k,
-                              exclude_self=exclude_self, row_offset=lo, col_offset=0, wait_event=ev_full,
-                              col_splits=col_splits, profile=return_stats, return_stats=return_stats)
+    out = ops.simtopk_panels(x_local, full, q, c_scal, panels, max_all, operand=operand, metric=metric, lam=lam, k=k,
+                             exclude_self=exclude_self, row_offset=lo, col_offset=0, wait_event=ev_full,
+                             col_splits=col_splits, profile=return_stats, return_stats=return_stats)
+    if return_stats:
+        out[2]["panels"] = len(panels)
+        out[2]["own_first"] = bool(own_first)
+    return out
 
 
 def pick_driver(x_local: torch.Tensor, n_total: int, world: int, *, metric="cosine", k: int = 5, exclude_self: bool = True,
                 precision: str = "auto", overlap: Optional[bool] = None, op: Optional[Callable] = None) -> str:
     """Which of the two drivers sharded_simtopk runs for these arguments: "pipelined" or "simple".  Pure shape /
     argument logic (no collective, no device work), so every rank reaches the same answer on its own."""
-    if op is not None or world <= 1 or overlap is False or not x_local.is_cuda or not isinstance(metric, str):
+    if op is not None or overlap is False or not x_local.is_cuda or not isinstance(metric, str):
         return "simple"
+    if world <= 1 and overlap is not True:     # overlap=True: the pipelined driver even for one rank (its collectives,
+        return "simple"                        # events and panel hand-off run on a one-GPU box: tests/test_gpu_distributed.py)
     from . import ops as _ops
     if (n_total % world) == 0 and precision in ("auto", "fast", "fast_bf16") \
             and _ops.fast_scan_supported(x_local.shape[1], k, exclude_self) \
@@ -218,7 +262,7 @@ def pick_driver(x_local: torch.Tensor, n_total: int, world: int, *, metric="cosi
 def sharded_simtopk(x_local: torch.Tensor, n_total: int, *, metric="cosine", lam: float = 1.0, k: int = 5,
                     exclude_self: bool = True, precision: str = "auto", group=None, gather_output: bool = False,
                     op: Optional[Callable] = None, return_stats: bool = False, overlap: Optional[bool] = None,
-                    chunks: Optional[int] = None, col_splits: int = 0):
+                    chunks: Optional[int] = None, col_splits: int = 0, own_first: Optional[bool] = None):
     """Top-k of every local row against ALL n_total rows.
 
     x_local: this rank's [N_r, d] shard (rows shard_bounds(n_total, world, rank)).
@@ -236,7 +280,8 @@ def sharded_simtopk(x_local: torch.Tensor, n_total: int, *, metric="cosine", lam
     if driver == "pipelined":
         out = _overlapped_simtopk(x_local.contiguous(), n_total, lo, hi, world, metric=metric, lam=lam, k=k,
                                   exclude_self=exclude_self, operand="bf16" if precision == "fast_bf16" else "f16",
-                                  group=group, return_stats=return_stats, chunks=chunks, col_splits=col_splits)
+                                  group=group, return_stats=return_stats, chunks=chunks, col_splits=col_splits,
+                                  own_first=own_first)
         idx, val = out[0], out[1]
         if gather_output:
             idx = all_gather_rows(idx, n_total, group)

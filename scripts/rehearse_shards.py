@@ -63,6 +63,14 @@ for N, d, metric, scale, dt in cases:
     gi, gv = dmod.sharded_simtopk(X[lo:hi].clone(), N, metric=metric, lam=0.5, k=5, gather_output=True)
     assert torch.equal(gi, ref_i) and (torch.allclose(gv, ref_v, rtol=0, atol=1e-5) if metric == "rbf" else torch.equal(gv, ref_v))
 
+# the exchange order without "own rows first" (every column out of the gathered chunks) stays selectable
+X = make_rows(0, 16384, 512, dev)
+for S in (1, 2, 4):
+    drv, _, _ = check(X, 16384, f"own_first=False chunks={S}", metric="cosine", k=5, own_first=False, chunks=S)
+    assert drv == "pipelined"
+st = dmod.sharded_simtopk(X[slice(*dmod.shard_bounds(16384, world, rank))].clone(), 16384, metric="cosine", k=5, return_stats=True)[2]
+assert st["own_first"] is True and st["panels"] == 1 + (1 if rank > 0 else 0) + (1 if rank < world - 1 else 0), st
+
 # bf16 scan operands, forced chunking / column splits, larger k
 X = make_rows(0, 16384, 512, dev)
 check(X, 16384, "fast_bf16 chunks=2", metric="cosine", k=5, precision="fast_bf16", chunks=2)

@@ -97,7 +97,25 @@ def test_chunk_layout_of_the_pipelined_exchange_maps_back_to_global_columns():
             assert np.array_equal(mapped, gathered), (world, rows, S, c)
             seen.append(mapped)
         assert np.array_equal(np.sort(np.concatenate(seen)), np.arange(n))
+    # own rows first (the default for world > 1): the rank's own rows, then each gathered chunk as the column ranges either
+    # side of the own segment — panels of rank `me` tile [0, N) without touching its own rows twice
+    for world, rows, S in ((8, 64, 1), (8, 64, 4), (4, 30, 2), (2, 12, 3), (3, 7, 1)):
+        n = world * rows
+        seg = rows // S
+        for me in range(world):
+            seen = [me * rows + np.arange(rows)]
+            for c in range(S):
+                gathered = np.concatenate([r * rows + c * seg + np.arange(seg) for r in range(world)])
+                i = np.arange(me * seg)
+                lo_ids = c * seg + (i // seg) * rows + i % seg
+                assert np.array_equal(lo_ids, gathered[:me * seg])
+                i = np.arange((world - 1 - me) * seg)
+                hi_ids = (me + 1) * rows + c * seg + (i // seg) * rows + i % seg
+                assert np.array_equal(hi_ids, gathered[(me + 1) * seg:])
+                seen += [lo_ids, hi_ids]
+            assert np.array_equal(np.sort(np.concatenate(seen)), np.arange(n)), (world, rows, S, me)
     assert dmod._pick_chunks(32768, 8, None) == 4 and dmod._pick_chunks(1000, 2, None) == 1
+    assert dmod._pick_chunks(32768, 8, None, own_first=True) == 1 and dmod._pick_chunks(32768, 8, 4, own_first=True) == 4
     assert dmod._pick_chunks(32768, 8, 2) == 2
     with pytest.raises(ValueError):
         dmod._pick_chunks(1000, 2, 3)

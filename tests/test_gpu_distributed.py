@@ -6,7 +6,8 @@ only walks the simple driver): the pipelined driver end to end — sharded prepa
 cached buffers, per-panel arrival events recorded on the side stream, paneled scan with shared thresholds, f32 rows
 waited for only in front of the re-rank — for all four metrics, f32 / f16 / bf16 rows, f16 / bf16 operands,
 gather_output, and repeated calls that reuse the cached buffers with fewer rows / other d.
-What it cannot cover: RCCL itself (async all-gathers on the backend's stream) needs more than one GPU.
+RCCL itself: test_rccl_code_path_with_one_rank runs the pipelined driver on backend "nccl" with one rank (the
+collectives, events and hand-off on real RCCL); more than one rank over xGMI needs the driver's multi-GPU node.
 """
 import json
 import os
@@ -42,6 +43,17 @@ def test_rehearsal_both_drivers_equal_unsharded(world):
     assert out.returncode == 0, tail
     assert "REHEARSAL OK" in out.stdout and "MISMATCH" not in out.stdout, tail
     assert "driver=pipelined" in out.stdout and "driver=simple" in out.stdout
+
+
+def test_rccl_code_path_with_one_rank():
+    """Backend "nccl" (RCCL) with world_size 1 in a fresh child: the asynchronous all-gathers on the backend's stream,
+    work.wait() on the side stream and the ready_event / select_wait_event hand-off into the paneled scan run on real
+    RCCL; results equal mmf.simtopk bit for bit (scripts/rccl_one_rank.py)."""
+    out = _torchrun(1, [os.path.join(ROOT, "scripts", "rccl_one_rank.py")])
+    tail = (out.stdout[-3000:] + "\n---- stderr ----\n" + out.stderr[-3000:])
+    assert out.returncode == 0, tail
+    assert "RCCL ONE RANK OK" in out.stdout and "MISMATCH" not in out.stdout, tail
+    assert "chunks=4 rep=1: panels=4" in out.stdout, tail
 
 
 def test_bench_two_ranks_is_self_checking():
