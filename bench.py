@@ -220,7 +220,7 @@ def main() -> None:
         roof.update({"prep_ms": stats["prep_ms"], "rerank_ms": stats["rerank_ms"], "fallback_ms": stats["fallback_ms"]})
         par = {"single": "single GPU",
                "simple": f"row-shard x{world}; one all-gather of the f32 shard",
-               "pipelined": f"row-shard x{world}; 16-bit operands all-gathered in chunks under the scan, f32 shard under all of it"}[driver]
+               "pipelined": f"row-shard x{world}; own rows scanned first, 16-bit operands of the other ranks all-gathered under that scan, f32 shard under all of it"}[driver]
         line = {
             "metric": "similarity-pairs/sec (NxN cosine+top-k)", "value": pairs / (elapsed / args.steps),
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -216,15 +216,16 @@ __device__ __forceinline__ void km_tile_dots(const float* const rowp[2], const f
 #pragma unroll
     for (int u = 0; u < NB; ++u) rb[st][u] = *reinterpret_cast<const float4*>(ptp[u] + c * KM_KC);
   };
-  auto swrite = [&](int st, int buf) {
+  // piece `part` (0 .. 3) of writing register stage `st` into LDS buffer `buf`: the conversions and LDS writes of the next
+  // chunk are spread between the MFMA groups of the current one, where they issue while the matrix pipe is busy
+  auto swrite_part = [&](int st, int buf, int part) {
     double* An = As + buf * (KM_T * KM_LD);
     double* Bn = Bs + buf * (KM_T * KM_LD);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) km_stage_store(An + (sr + 32 * u) * KM_LD + sk, ra[st][u]);
-#pragma unroll
-    for (int u = 0; u < NB; ++u) km_stage_store(Bn + (sr + 32 * u) * KM_LD + sk, rb[st][u]);
+    if (part < 2) km_stage_store(An + (sr + 32 * part) * KM_LD + sk, ra[st][part]);
+    else if (part - 2 < NB) km_stage_store(Bn + (sr + 32 * (part - 2)) * KM_LD + sk, rb[st][part - 2]);
   };
-  auto compute = [&](int buf) {
+  // chunk in LDS buffer `buf` -> accumulators; behind MFMA group q, piece q of the staging of stage `st` into the other buffer
+  auto compute = [&](int buf, int st) {
     const double* A = As + buf * (KM_T * KM_LD) + (arow0 + (lane & 15)) * KM_LD + 2 * g;
     const double* B = Bs + buf * (KM_T * KM_LD) + (bpt + (lane & 15)) * KM_LD + 2 * g;
 #pragma unroll
@@ -237,22 +238,25 @@ __device__ __forceinline__ void km_tile_dots(const float* const rowp[2], const f
       for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b.x, acc[m], 0, 0, 0);
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b.y, acc[m], 0, 0, 0);
+      swrite_part(st, buf ^ 1, q);
     }
   };
+  const int64_t lastc = nchunks - 1;
   gload(0, 0);
-  if (nchunks > 1) gload(1, 1);
-  swrite(0, 0);
+  gload(1, lastc < 1 ? lastc : 1);
+#pragma unroll
+  for (int part = 0; part < 4; ++part) swrite_part(0, 0, part);
   __syncthreads();
-  // chunk c is in LDS buffer c & 1, chunk c + 1 in register stage (c + 1) & 1; chunk c + 2 is requested into stage c & 1
+  // chunk c is in LDS buffer c & 1, chunk c + 1 in register stage (c + 1) & 1; chunk c + 2 is requested into stage c & 1.
+  // No branches inside an iteration (chunk indices past the end are clamped: their loads and LDS writes are harmless), so the
+  // staging interleaves with the MFMAs.
   for (int64_t c = 0; c < nchunks; c += 2) {
-    if (c + 2 < nchunks) gload(0, c + 2);
-    compute(0);
-    if (c + 1 < nchunks) swrite(1, 1);
+    gload(0, c + 2 < lastc ? c + 2 : lastc);      // stage 0 (chunk c) went into LDS during the previous iteration
+    compute(0, 1);                               // reads buffer 0, stages chunk c + 1 (stage 1) into buffer 1
     __syncthreads();
     if (c + 1 >= nchunks) break;
-    if (c + 3 < nchunks) gload(1, c + 3);
-    compute(1);
-    if (c + 2 < nchunks) swrite(0, 0);
+    gload(1, c + 3 < lastc ? c + 3 : lastc);
+    compute(1, 0);                               // reads buffer 1, stages chunk c + 2 (stage 0) into buffer 0
     __syncthreads();
   }
 }

@@ -21,7 +21,11 @@ for N, D, S in ((4096, 128, 100), (16384, 512, 100), (65536, 512, 100)):
     T = torch.from_numpy((cent[rng.randint(0, 200, 256)] * 0.3 + 0.05 * rng.randn(256, D)).astype(np.float32)).cuda()
     for backend in ("device", "sklearn"):
         pp.set_kmeans_backend(backend)
-        b.aggregate_wsi_super_patches(W[:512], P[:512], 8)      # warm-up
+        b.aggregate_wsi_super_patches(W[:512], P[:512], 8)      # warm-up: kernels loaded, workspaces grown
+        _sf, _sp, _st, _K = b.aggregate_wsi_super_patches(W[:2048], P[:2048], S, 0.5, 1.0)
+        _sim, _ = b.compute_wsi_tma_similarity(_sf, _sp, T, 0.5, 1.0)
+        _gl, _ = b.group_by_similarity(_sim, 10)
+        b.build_hypergraph_knn_kmeans(_sf, T, _gl, 5, 10)
         ms_k, _ = t(lambda: pp._kmeans_labels(W, S))
         if N <= 16384:
             ms_a, (sf, sp, st, K) = t(lambda: b.aggregate_wsi_super_patches(W, P, S, 0.5, 1.0))
