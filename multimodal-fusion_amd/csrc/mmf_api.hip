@@ -170,6 +170,7 @@ struct FastTail {
   int32_t *fail_rows = nullptr, *fb_fail_rows = nullptr;
   uint32_t *fail_count = nullptr, *cand_total = nullptr, *fb_fail_count = nullptr;
   char* scan_scratch = nullptr;
+  char* order_scratch = nullptr;
 
   int dp, panels;
   int panel_splits[16]; int max_splits = 1;
@@ -225,7 +226,7 @@ struct FastTail {
     return ws_bytes((size_t)n * lists, 4) + 2 * ws_bytes((size_t)n * lists * bcap, 4) + 3 * ws_bytes(n, 4) + ws_bytes(4, 4) +
            ws_bytes(256, 4) + ws_bytes((size_t)FB * fb_lists, 4) + ws_bytes((size_t)FB * fb_lists * cap, 4) +
            2 * ws_bytes(FB, 4) + ws_bytes(4, 4) + ws_bytes(scan_b16_scratch_bytes(n, max_splits, dp, bcap), 1) + ws_bytes(2 * n_seed, 4) +
-           ws_bytes((size_t)rows_exact_cap * m, 4) + ws_bytes(n, 4) + ws_bytes((size_t)n * kSpillCap, 4);
+           ws_bytes((size_t)rows_exact_cap * m, 4) + ws_bytes(n, 4) + ws_bytes((size_t)n * kSpillCap, 4) + ws_bytes(select_order_bytes(n), 1);
   }
   void carve(Workspace& ws) {
     L.cnt = ws.take<uint32_t>((size_t)n * lists);
@@ -250,6 +251,7 @@ struct FastTail {
     L.spill_cnt = ws.take<uint32_t>(n);
     L.spill_ids = ws.take<uint32_t>((size_t)n * kSpillCap);
     L.spill_cap = kSpillCap;
+    order_scratch = ws.take<char>(select_order_bytes(n));
   }
   int run(const void* X, int64_t n_, const void* Y, int64_t m_, int64_t d, int in_dtype, int metric, float lambda, int k,
           int exclude_self, int64_t row_offset, int64_t col_offset, const FastOperands& fo, int64_t* out_idx,
@@ -301,6 +303,7 @@ struct FastTail {
     q.rx = fo.rx; q.cy = fo.cy; q.row_ids = nullptr; q.n_rows = n; q.out_idx = out_idx; q.out_val = out_val;
     q.fail_rows = fail_rows; q.fail_count = fail_count; q.cand_total = stats ? cand_total : nullptr;
     q.two_pass = true;
+    q.order_scratch = getenv("MMF_SELECT_UNORDERED") ? nullptr : order_scratch;
     MMF_TRY(t_sel.start(profile, s));
     MMF_TRY(launch_select(q, L, s));
     MMF_TRY(t_sel.stop(s));

@@ -148,7 +148,9 @@ struct SelectProblem {
   int32_t* fail_rows; uint32_t* fail_count;   // rows whose lists overflowed (or came up short)
   uint32_t* cand_total;                        // optional accumulated candidate count
   bool two_pass = false;   // rows with overflow-list entries are handled by a second launch that has LDS room for them
+  void* order_scratch = nullptr;   // select_order_bytes(n_rows): that second launch walks its rows ordered by their smallest candidate id
 };
+size_t select_order_bytes(int64_t n);
 int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s);
 // exact top-k of a few rows (p.row_ids) against every column, no candidate lists; keys: p.n_rows * p.m floats
 int launch_rows_exact(const SelectProblem& p, float* keys, hipStream_t s);

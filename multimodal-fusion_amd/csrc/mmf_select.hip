@@ -8,6 +8,8 @@
 // splits or shard counts.
 // Replaces: "indices[i, 1:]" (drop column 0) of preprocess_hypergraph.py:386-388 and the score
 //           passes of similarity_kernel.py:49-52 for the pairs that survive.
+#include <hipcub/hipcub.hpp>
+
 #include "mmf_dev.h"
 #include "mmf_host.h"
 
@@ -28,6 +30,12 @@ struct SelectArgs {
   // staged kernel, two passes when overflow lists exist: pass 0 handles the rows without overflow entries in a lean
   // LDS footprint and queues the others; pass 1 (room for the overflow entries) takes the queue
   int pass; int two_pass;
+  // ordered second pass (near-duplicate data): pass 0 leaves a sort key per row — the smallest candidate id of a row that
+  // waits for pass 1, 0xffffffff otherwise — and pass 1 walks the rows in key order, a contiguous eighth of that order per
+  // XCD: rows whose candidate sets coincide (the members of a cluster) are re-ranked next to each other and find each
+  // other's candidate rows in that XCD's L2 instead of gathering them from HBM again.
+  uint32_t* key_in; uint32_t* row_in;              // pass 0 writes
+  const uint32_t* key_sorted; const uint32_t* row_sorted;   // pass 1 reads
   int64_t* out_idx; float* out_val;
   int32_t* fail_rows; uint32_t* fail_count; uint32_t* cand_total;
   int maxc;   // staged kernel: candidate slots per wave in dynamic LDS
@@ -240,7 +248,9 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_kernel(SelectArgs a) {
 // canonical k-ordered chains run out of LDS (row stride 132 floats: conflict-free ds_read_b128),
 // one lane per candidate.  SG = 8 for the common launch (6.5 candidates per row on Gaussian data: half the LDS, 24
 // instead of 16 waves per CU, re-rank 1.35 -> 1.04 ms at N = 262144), 16 for the launch that takes the rows with
-// overflow-list entries (129 candidates per row on clustered data: fewer group rounds, 11.6 -> 10.7 ms).
+// overflow-list entries (129 candidates per row on clustered data: fewer group rounds, 11.6 -> 10.7 ms), 32 since round 3
+// (with the rows of that launch ordered by their smallest candidate id: 10.8 -> 8.9 ms; the launch is bound by LDS reads —
+// two ds_read_b128 per four fmaf of a lane — not by the gathers, which is why neither change buys more).
 constexpr int SC = 128;
 constexpr int SLD = SC + 4;
 
@@ -275,13 +285,37 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
   float* skey_base = reinterpret_cast<float*>(sel_smem + sizeof(float) * SEL_WAVES * (SG * SLD + SC));
   uint32_t* sid_base = reinterpret_cast<uint32_t*>(skey_base + SEL_WAVES * maxc);
   int64_t pos = (int64_t)blockIdx.x * SEL_WAVES + wave;
-  if (pos >= a.n_rows) return;
-  if (a.two_pass) {
-    // two passes: rows with overflow entries wait for the second launch, which has LDS room for them.  Both launches
-    // cover every row and a row decides by its own counters which one it belongs to (a queue filled through one
-    // atomic counter cost 25 cycles per row at the L2 when every row has overflow entries, i.e. on clustered data).
-    const bool deferred = a.overflow[pos] == 0 && a.spill_cnt[pos] != 0;
-    if (deferred != (a.pass == 1)) return;
+  if (a.pass == 1 && a.key_sorted) {
+    // block b -> chunk (b % 8) * (blocks / 8) + b / 8 of the sorted order (the grid is a multiple of 8 blocks)
+    const int64_t per = gridDim.x >> 3;
+    const int64_t slot = (((int64_t)blockIdx.x & 7) * per + ((int64_t)blockIdx.x >> 3)) * SEL_WAVES + wave;
+    if (slot >= a.n_rows || a.key_sorted[slot] == 0xffffffffu) return;
+    pos = (int64_t)a.row_sorted[slot];
+  } else {
+    if (pos >= a.n_rows) return;
+    if (a.two_pass) {
+      // two passes: rows with overflow entries wait for the second launch, which has LDS room for them.  Both launches
+      // cover every row and a row decides by its own counters which one it belongs to (a queue filled through one
+      // atomic counter cost 25 cycles per row at the L2 when every row has overflow entries, i.e. on clustered data).
+      const bool deferred = a.overflow[pos] == 0 && a.spill_cnt[pos] != 0;
+      if (a.key_in && a.pass == 0) {
+        uint32_t mn = 0xffffffffu;
+        if (deferred) {
+          for (int l = 0; l < a.lists; ++l) {
+            const uint32_t cn = a.cand_cnt[pos * a.lists + l];
+            for (uint32_t e = lane; e < cn; e += 64) { const uint32_t v = a.cand_ids[(pos * a.lists + l) * a.cap + e]; mn = v < mn ? v : mn; }
+          }
+          const uint32_t c = a.spill_cnt[pos];
+          const uint32_t nsp = c < (uint32_t)a.spill_cap ? c : (uint32_t)a.spill_cap;
+          for (uint32_t e = lane; e < nsp; e += 64) { const uint32_t v = a.spill_ids[pos * a.spill_cap + e]; mn = v < mn ? v : mn; }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)mn, o); mn = v < mn ? v : mn; }
+          if (mn == 0xffffffffu) mn = 0xfffffffeu;     // a waiting row always carries a key below the "not waiting" marker
+        }
+        if (lane == 0) { a.key_in[pos] = mn; a.row_in[pos] = (uint32_t)pos; }
+      }
+      if (deferred != (a.pass == 1)) return;
+    }
   }
   const int64_t row = a.row_ids ? (int64_t)a.row_ids[pos] : pos;
   float* key = skey_base + wave * maxc;
@@ -408,7 +442,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
 }
 
 template <int METRIC>
-static int launch_select_m(const SelectArgs& a, bool vec4, bool staged16, hipStream_t s) {
+static int launch_select_m(const SelectArgs& a, bool vec4, bool staged16, void* order_temp, size_t order_temp_bytes, hipStream_t s) {
   const int64_t grid = (a.n_rows + SEL_WAVES - 1) / SEL_WAVES;
   if ((vec4 || staged16) && a.d >= 64) {
     const bool two = a.spill_cnt != nullptr && a.two_pass && a.row_ids == nullptr;
@@ -418,20 +452,41 @@ static int launch_select_m(const SelectArgs& a, bool vec4, bool staged16, hipStr
       if (!two) b.two_pass = 0;
       const int extra = (two && pass == 0) ? 0 : a.spill_cap;
       b.maxc = ((a.lists * a.cap + extra + 63) / 64) * 64;
-      const int sg = (extra == 0) ? 8 : 16;       // rows with overflow entries carry many candidates
-      auto kern = sg == 8 ? (a.dtype == MMF_F32 ? select_staged_kernel<METRIC, MMF_F32, 8>
-                             : (a.dtype == MMF_BF16 ? select_staged_kernel<METRIC, MMF_BF16, 8> : select_staged_kernel<METRIC, MMF_F16, 8>))
-                          : (a.dtype == MMF_F32 ? select_staged_kernel<METRIC, MMF_F32, 16>
-                             : (a.dtype == MMF_BF16 ? select_staged_kernel<METRIC, MMF_BF16, 16> : select_staged_kernel<METRIC, MMF_F16, 16>));
+      int sg = (extra == 0) ? 8 : 32;       // rows with overflow entries carry many candidates
+      if (extra != 0) if (const char* e = getenv("MMF_SELECT_SG")) { const int v = atoi(e); if (v == 16 || v == 32) sg = v; }
+      auto kern = a.dtype == MMF_F32 ? select_staged_kernel<METRIC, MMF_F32, 8>
+                  : (a.dtype == MMF_BF16 ? select_staged_kernel<METRIC, MMF_BF16, 8> : select_staged_kernel<METRIC, MMF_F16, 8>);
+      if (sg == 16) kern = a.dtype == MMF_F32 ? select_staged_kernel<METRIC, MMF_F32, 16>
+                           : (a.dtype == MMF_BF16 ? select_staged_kernel<METRIC, MMF_BF16, 16> : select_staged_kernel<METRIC, MMF_F16, 16>);
+      if (sg == 32) kern = a.dtype == MMF_F32 ? select_staged_kernel<METRIC, MMF_F32, 32>
+                           : (a.dtype == MMF_BF16 ? select_staged_kernel<METRIC, MMF_BF16, 32> : select_staged_kernel<METRIC, MMF_F16, 32>);
       const size_t lds = sizeof(float) * SEL_WAVES * (sg * SLD + SC) + (size_t)SEL_WAVES * b.maxc * 8;
       MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * SEL_WAVES), lds, s, b);
+      int64_t g = grid;
+      if (pass == 1 && a.key_in) {                    // order the waiting rows by their smallest candidate id
+        size_t tb = order_temp_bytes;
+        MMF_HIP(hipcub::DeviceRadixSort::SortPairs(order_temp, tb, a.key_in, const_cast<uint32_t*>(a.key_sorted), a.row_in,
+                                                   const_cast<uint32_t*>(a.row_sorted), (int)a.n_rows, 0, 32, s));
+        g = (grid + 7) / 8 * 8;
+      } else if (pass == 1) {
+        b.key_sorted = nullptr;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(64 * SEL_WAVES), lds, s, b);
       MMF_LAUNCH_CHECK();
     }
   } else if (vec4) hipLaunchKernelGGL((select_kernel<METRIC, true>), dim3((unsigned)grid), dim3(64 * SEL_WAVES), 0, s, a);
   else hipLaunchKernelGGL((select_kernel<METRIC, false>), dim3((unsigned)grid), dim3(64 * SEL_WAVES), 0, s, a);
   MMF_LAUNCH_CHECK();
   return MMF_OK;
+}
+
+// scratch of the ordered second pass: four u32 arrays of n (rounded to 64) + the radix sort's temporary storage
+size_t select_order_bytes(int64_t n) {
+  const size_t nn = ((size_t)n + 63) & ~size_t(63);
+  size_t tb = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                           (int)n, 0, 32, (hipStream_t)0);
+  return 4 * nn * 4 + ((tb + 255) & ~size_t(255)) + 256;
 }
 
 int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
@@ -449,6 +504,15 @@ int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
   a.cand_keys = L.keys; a.margin = L.margin; a.slot_ulp = L.slot_ulp;
   a.spill_cnt = L.spill_cnt; a.spill_ids = L.spill_ids; a.spill_cap = L.spill_cap;
   a.pass = 0; a.two_pass = p.two_pass ? 1 : 0;
+  void* order_temp = nullptr;
+  size_t order_temp_bytes = 0;
+  if (p.two_pass && p.order_scratch && p.row_ids == nullptr && L.spill_cnt) {
+    uint32_t* o = static_cast<uint32_t*>(p.order_scratch);
+    const size_t nn = ((size_t)p.n_rows + 63) & ~size_t(63);
+    a.key_in = o; a.row_in = o + nn; a.key_sorted = o + 2 * nn; a.row_sorted = o + 3 * nn;
+    order_temp = o + 4 * nn;
+    order_temp_bytes = select_order_bytes(p.n_rows) - 4 * nn * 4;
+  }
   a.out_idx = p.out_idx; a.out_val = p.out_val;
   a.fail_rows = p.fail_rows; a.fail_count = p.fail_count; a.cand_total = p.cand_total;
   const bool v4 = p.dtype == MMF_F32 && (p.d % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0) &&
@@ -457,10 +521,10 @@ int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
   const bool s16 = p.dtype != MMF_F32 && (p.d % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 7) == 0) &&
                    ((reinterpret_cast<uintptr_t>(p.Y) & 7) == 0);
   switch (p.metric) {
-    case MMF_DOT: return launch_select_m<MMF_DOT>(a, v4, s16, s);
-    case MMF_COSINE: return launch_select_m<MMF_COSINE>(a, v4, s16, s);
-    case MMF_NEG_SQ_L2: return launch_select_m<MMF_NEG_SQ_L2>(a, v4, s16, s);
-    case MMF_RBF: return launch_select_m<MMF_RBF>(a, v4, s16, s);
+    case MMF_DOT: return launch_select_m<MMF_DOT>(a, v4, s16, order_temp, order_temp_bytes, s);
+    case MMF_COSINE: return launch_select_m<MMF_COSINE>(a, v4, s16, order_temp, order_temp_bytes, s);
+    case MMF_NEG_SQ_L2: return launch_select_m<MMF_NEG_SQ_L2>(a, v4, s16, order_temp, order_temp_bytes, s);
+    case MMF_RBF: return launch_select_m<MMF_RBF>(a, v4, s16, order_temp, order_temp_bytes, s);
   }
   set_error("select: unsupported metric %d", p.metric);
   return MMF_E_INVALID;
