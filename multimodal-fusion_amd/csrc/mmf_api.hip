@@ -184,7 +184,8 @@ struct FastTail {
   int64_t rows_exact_cap = 0;
   float* row_keys = nullptr;
   // m_panel_min: columns of the smallest panel (== m_ when the scan is one launch); `splits` is per launch
-  FastTail(int64_t n_, int64_t m_, int kk_, int cap_, int forced_splits, int dp_, int panels_ = 1, int64_t m_panel_min = -1)
+  FastTail(int64_t n_, int64_t m_, int kk_, int cap_, int forced_splits, int dp_, int panels_ = 1, int64_t m_panel_min = -1,
+           int64_t m_panel_max = -1)
       : n(n_), m(m_), kk(kk_), cap(cap_), dp(dp_), panels(panels_) {
     bcap = scan_bf16_cap(kk);
     const int qt = scan_b16_queries_per_block(dp);
@@ -195,6 +196,13 @@ struct FastTail {
     if (forced_splits > 0) { while (splits < forced_splits) splits <<= 1; }
     else { while (row_blocks * splits < 256 && splits < 32) splits <<= 1; }
     while (splits > 1 && (splits > col_tiles || 2 * splits * panels * bcap > 1024 - kSpillCap)) splits >>= 1;
+    // the tile DMA addresses a workgroup's column range with 32-bit offsets: a range stays under 4 GiB of 16-bit operands
+    // (N = 4 M rows at d = 1024 is 8 GiB: at least four splits), whatever the caller forced
+    {
+      const int64_t m_big = (m_panel_max > 0 ? m_panel_max : m);
+      const int64_t range_bytes = ((m_big + 255) / 256 * 256) * (int64_t)dp * 2;
+      while ((range_bytes + splits - 1) / splits >= (int64_t(1) << 32) && 2 * (2 * splits) * panels * bcap <= 1024 - kSpillCap) splits <<= 1;
+    }
     // The first half of the panels runs while the rest of the exchange is still on the wire and its kernel
     // holds compute units.  MMF_PANEL_FRONT_FACTOR = 2 or 4 gives those launches that many times the workgroups
     // (shorter ones), which shortens the tail the late-joining units leave — measured with a stand-in kernel
@@ -697,7 +705,7 @@ int mmf_simtopk_panels(const void* X, int64_t n, const void* Y, int64_t m, int64
   if (operand != MMF_F16 && operand != MMF_BF16) { set_error("simtopk_panels: bad operand"); return MMF_E_INVALID; }
   if (k < 1) { set_error("simtopk_panels: k must be >= 1"); return MMF_E_INVALID; }
   if (n_panels < 1 || n_panels > 16) { set_error("simtopk_panels: n_panels must be in 1..16"); return MMF_E_INVALID; }
-  int64_t covered = 0, m_min = m;
+  int64_t covered = 0, m_min = m, m_max = 0;
   for (int p = 0; p < n_panels; ++p) {
     const mmf_panel& P = panels[p];
     if (!P.Z || !P.cb || P.m < 1 || P.m_pad < P.m || (P.m_pad % 256) != 0 || P.seg_len < 0 || P.id_base < 0 ||
@@ -708,6 +716,7 @@ int mmf_simtopk_panels(const void* X, int64_t n, const void* Y, int64_t m, int64
     if (last >= m) { set_error("simtopk_panels: panel %d maps past column %lld", p, (long long)m); return MMF_E_INVALID; }
     covered += P.m;
     if (P.m < m_min) m_min = P.m;
+    if (P.m_pad > m_max) m_max = P.m_pad;
   }
   if (covered != m) { set_error("simtopk_panels: panels cover %lld columns, Y has %lld", (long long)covered, (long long)m); return MMF_E_INVALID; }
   if (stats) memset(stats, 0, sizeof(*stats));
@@ -722,7 +731,7 @@ int mmf_simtopk_panels(const void* X, int64_t n, const void* Y, int64_t m, int64
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   DeviceGuard guard(device_id);
   if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
-  FastTail ft(n, m, kk, cap, opts ? opts->col_splits : 0, scan_bf16_dp(d), n_panels, m_min);
+  FastTail ft(n, m, kk, cap, opts ? opts->col_splits : 0, scan_bf16_dp(d), n_panels, m_min, m_max);
   if ((int64_t)ft.lists * ft.bcap + FastTail::kSpillCap > 1024) {
     set_error("simtopk_panels: %d panels x %d-entry lists exceed the 1024 candidates a row can hand to the re-rank (k = %d): use fewer panels", n_panels, ft.bcap, k);
     return MMF_E_UNSUPPORTED;

@@ -584,7 +584,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
           m0_prev = max_qb(acc_prev, 0);
           m1_prev = max_qb(acc_prev, 1);
         }
-        if (lane == 0) ack[qw] = j;  // the exchange block may be overwritten (LDS operations of a wave complete in order)
+        // the reads of the exchange block above must be ISSUED before the acknowledgement below (LDS operations of a wave
+        // complete in order, so issue order is all it takes): keep the compiler from sinking them past the volatile store
+        asm volatile("" ::: "memory");
+        if (lane == 0) ack[qw] = j;  // the exchange block may be overwritten
       }
     }
     if (owner) filter(acc_prev, j * TPB - 1, m0_prev, m1_prev);  // behind the barrier: only this wave waits for its own list code
@@ -620,6 +623,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
         } else if (!owner) {
           // hand this tile's partial sums to the lower-half wave once it has taken the previous tile's
           while (ack[qw] < j) __builtin_amdgcn_s_sleep(1);
+          asm volatile("" ::: "memory");        // ... and the writes of the next partials stay behind the poll
 #pragma unroll
           for (int i = 0; i < 4; ++i) xch[(qw * 4 + i) * 64 + lane] = acc.t[i >> 1][i & 1];
           __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the partials are in LDS before this wave reaches the barrier

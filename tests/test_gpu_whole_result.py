@@ -140,3 +140,20 @@ def test_k32_wide_lists_every_row(mmf):
     Xc = centers[assign] + 0.03 * torch.randn((32768, 256), generator=g, device="cuda") / 256 ** 0.5
     Xc = Xc / Xc.norm(dim=1, keepdim=True)
     whole_result(mmf, Xc, None, "neg_sq_l2", 24, True, precisions=("fast",), oracle_rows=32)
+
+
+def test_column_range_above_4gib_splits_by_itself(mmf):
+    """N = 2.4 M columns at d = 1024 are 4.9 GiB of 16-bit operands: more than the tile DMA's 32-bit offsets address from
+    one base, so the library raises the column splits on its own (round 2: an error asking the caller for col_splits).
+    512 query rows against all columns: the 16-bit scan against the exact scan, every row."""
+    M, d, n = 2400000, 1024, 512
+    Y = torch.empty((M, d), dtype=torch.float16, device="cuda")
+    for b in range(0, M, 100000):
+        g = torch.Generator(device="cuda").manual_seed(9000 + b)
+        blk = torch.randn((min(100000, M - b), d), generator=g, device="cuda", dtype=torch.float32)
+        Y[b:b + blk.shape[0]] = (blk / blk.norm(dim=1, keepdim=True)).half()
+    X = Y[1200000:1200000 + n]
+    fi, fv, st = mmf.simtopk(X, Y, metric="cosine", k=5, exclude_self=True, row_offset=1200000, precision="fast", return_stats=True)
+    assert st["precision_used"] == 2 and st["col_splits"] >= 2 and st["fallback_rows"] == 0, st
+    ei, ev = mmf.simtopk(X, Y, metric="cosine", k=5, exclude_self=True, row_offset=1200000, precision="exact")
+    assert torch.equal(fi, ei) and torch.equal(fv, ev)
