@@ -290,6 +290,16 @@ int mmf_offdiag_lower_median(const float* K, int64_t n, float* out_median,
 int mmf_threshold_edges(const float* K, int64_t n, float threshold,
                         int64_t* edge_index, float* edge_w, int64_t capacity,
                         int64_t* out_count, int device_id, void* hip_stream);
+/*
+ * The same builder in two calls for a caller that sizes edge_index from the count (a torch front end): the counting pass
+ * leaves the rows' exclusive offsets (row_offsets[n + 1] device uint64, row_offsets[n] = *out_count), the fill pass takes
+ * them and writes edge_index [2, capacity] / edge_w [capacity] — K is read twice in all (mmf_threshold_edges called with
+ * capacity 0 and then again reads it three times).  K and threshold must be those of the counting call.
+ */
+int mmf_threshold_edges_count(const float* K, int64_t n, float threshold, uint64_t* row_offsets, int64_t* out_count,
+                              int device_id, void* hip_stream);
+int mmf_threshold_edges_fill(const float* K, int64_t n, float threshold, const uint64_t* row_offsets, int64_t* edge_index,
+                             float* edge_w, int64_t capacity, int device_id, void* hip_stream);
 
 /*
  * Order statistics of a flat f32 array already in HBM (any dense similarity matrix, or a vector of edge weights).

@@ -46,7 +46,7 @@ _lib = None
 
 EXPORTS = ["mmf_version", "mmf_last_error", "mmf_simtopk", "mmf_simtopk_ex", "mmf_row_scalars", "mmf_prep_rows",
            "mmf_simtopk_prepared", "mmf_simtopk_panels", "mmf_padded_dim", "mmf_fast_scan_supported", "mmf_topk_merge", "mmf_edge_cosine",
-           "mmf_sim_dense", "mmf_sim_dense_stats", "mmf_sim_dense_combined", "mmf_offdiag_lower_median", "mmf_threshold_edges", "mmf_lower_median", "mmf_array_stats",
+           "mmf_sim_dense", "mmf_sim_dense_stats", "mmf_sim_dense_combined", "mmf_offdiag_lower_median", "mmf_threshold_edges", "mmf_threshold_edges_count", "mmf_threshold_edges_fill", "mmf_lower_median", "mmf_array_stats",
            "mmf_segment_sort", "mmf_segment_mean", "mmf_segment_offdiag_mean", "mmf_clique_pairs", "mmf_knn_pairs", "mmf_kmeans_fit", "mmf_combined_offdiag_median", "mmf_combined_threshold_edges",
            "mmf_release_workspaces"]
 
@@ -91,6 +91,8 @@ def lib() -> ctypes.CDLL:
     L.mmf_lower_median.argtypes = [vp, i64, vp, ci, vp]
     L.mmf_array_stats.argtypes = [vp, i64, vp, ci, vp]
     L.mmf_threshold_edges.argtypes = [vp, i64, f32, vp, vp, i64, vp, ci, vp]
+    L.mmf_threshold_edges_count.argtypes = [vp, i64, f32, vp, vp, ci, vp]
+    L.mmf_threshold_edges_fill.argtypes = [vp, i64, f32, vp, vp, vp, i64, ci, vp]
     L.mmf_combined_offdiag_median.argtypes = [vp, vp, i64, i64, i64, f32, f32, i64, vp, ci, vp]
     L.mmf_combined_threshold_edges.argtypes = [vp, vp, i64, i64, i64, f32, f32, f32, i64, vp, vp, i64, vp, ci, vp]
     for name in EXPORTS:

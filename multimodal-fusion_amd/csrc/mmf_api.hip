@@ -1050,6 +1050,34 @@ int mmf_threshold_edges(const float* K, int64_t n, float threshold, int64_t* edg
                                 reinterpret_cast<uint32_t*>(ws.take<uint64_t>(rows_u32)), rows_u32 * 2, s);
 }
 
+int mmf_threshold_edges_count(const float* K, int64_t n, float threshold, uint64_t* row_offsets, int64_t* out_count, int device_id,
+                              void* hip_stream) {
+  if (device_id < 0) { set_error("threshold_edges_count: no CPU path"); return MMF_E_UNSUPPORTED; }
+  if (n < 0) { set_error("threshold_edges_count: bad n"); return MMF_E_INVALID; }
+  if (!out_count || !row_offsets) { set_error("threshold_edges_count: NULL pointer"); return MMF_E_INVALID; }
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  MMF_HIP(hipMemsetAsync(out_count, 0, 8, s));
+  if (n == 0) { MMF_HIP(hipMemsetAsync(row_offsets, 0, 8, s)); return MMF_OK; }
+  if (!K) { set_error("threshold_edges_count: NULL pointer"); return MMF_E_INVALID; }
+  Workspace ws;
+  MMF_TRY(get_workspace(device_id, s, ws_bytes((size_t)n, 4), &ws));
+  return launch_threshold_count(K, n, threshold, reinterpret_cast<unsigned long long*>(row_offsets), out_count, ws.take<uint32_t>((size_t)n), s);
+}
+
+int mmf_threshold_edges_fill(const float* K, int64_t n, float threshold, const uint64_t* row_offsets, int64_t* edge_index, float* edge_w,
+                             int64_t capacity, int device_id, void* hip_stream) {
+  if (device_id < 0) { set_error("threshold_edges_fill: no CPU path"); return MMF_E_UNSUPPORTED; }
+  if (n < 0 || capacity < 0) { set_error("threshold_edges_fill: bad n/capacity"); return MMF_E_INVALID; }
+  if (n == 0 || capacity == 0) return MMF_OK;
+  if (!K || !row_offsets || !edge_index || !edge_w) { set_error("threshold_edges_fill: NULL pointer"); return MMF_E_INVALID; }
+  DeviceGuard guard(device_id);
+  if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
+  return launch_threshold_fill(K, n, threshold, reinterpret_cast<const unsigned long long*>(row_offsets), edge_index, edge_w, capacity,
+                               static_cast<hipStream_t>(hip_stream));
+}
+
 // ---- the same two steps for an N whose K = K_h * K_g does not fit: K is recomputed in row panels -----------------
 static int64_t pick_panel_rows(int64_t n, int64_t panel_rows) {
   if (panel_rows <= 0) panel_rows = (int64_t(1) << 30) / (4 * n);     // about 1 GiB of f32 per panel

@@ -279,12 +279,28 @@ __global__ __launch_bounds__(1024) void bracket_bounds_kernel(const float* __res
   }
 }
 
+struct StatPartial { double s1, s2; float mn, mx; };
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+
+
 // K: rows [row0, row0 + rows) of a matrix with n columns; the entry (row0 + li, j == row0 + li) is skipped (pass
 // kNoDiagonal as row0 for data without a diagonal).  One wave per row, 16 bytes per lane when n % 4 == 0.
+// part != NULL: the sweep also leaves the workgroup's statistic partial (sums around pivot[0], minimum, maximum) over the entries
+// it visits — mmf_array_stats then reads its array once instead of twice.
 __global__ __launch_bounds__(256) void bracket_sweep_kernel(const float* __restrict__ K, int64_t n, int64_t row0, int64_t rows,
-                                                            BracketState* st, float* __restrict__ buf) {
+                                                            BracketState* st, float* __restrict__ buf, StatPartial* __restrict__ part,
+                                                            const float* __restrict__ pivot) {
   __shared__ float stage[4][1024];
   __shared__ unsigned long long wbelow[4];
+  __shared__ StatPartial wstat[4];
+  const double pv = part ? (double)pivot[0] : 0.0;
+  double s1 = 0.0, s2 = 0.0;
+  float smn = __builtin_huge_valf(), smx = -__builtin_huge_valf();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float lo = st->lo, hi = st->hi;
   const unsigned long long seg_cap = st->seg_cap;
@@ -304,6 +320,11 @@ __global__ __launch_bounds__(256) void bracket_sweep_kernel(const float* __restr
   auto offer = [&](float x, bool valid) {
     const bool in = valid && x >= lo && x <= hi;
     below += (valid && x < lo) ? 1ull : 0ull;
+    if (part && valid) {
+      const double dx = (double)x - pv;
+      s1 += dx; s2 = __builtin_fma(dx, dx, s2);
+      smn = fminf(smn, x); smx = fmaxf(smx, x);
+    }
     const unsigned long long mask = __ballot(in);
     if (in) stage[w][cnt + __popcll(mask & lt)] = x;
     cnt += __popcll(mask);
@@ -336,11 +357,22 @@ __global__ __launch_bounds__(256) void bracket_sweep_kernel(const float* __restr
     const unsigned long long lo32 = (unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)below, o);
     below += (hi32 << 32) | lo32;
   }
+  if (part) {
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { smn = fminf(smn, __shfl_xor(smn, o)); smx = fmaxf(smx, __shfl_xor(smx, o)); }
+    if (lane == 0) wstat[w] = StatPartial{s1, s2, smn, smx};
+  }
   if (lane == 0) wbelow[w] = below;
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned long long t = wbelow[0] + wbelow[1] + wbelow[2] + wbelow[3];
     if (t) atomicAdd(&st->below[(blockIdx.x % (unsigned)kBracketSegs) * kBracketPad], t);
+    if (part) {
+      StatPartial r = wstat[0];
+      for (int i = 1; i < 4; ++i) { r.s1 += wstat[i].s1; r.s2 += wstat[i].s2; r.mn = fminf(r.mn, wstat[i].mn); r.mx = fmaxf(r.mx, wstat[i].mx); }
+      part[blockIdx.x] = r;
+    }
   }
 }
 
@@ -416,8 +448,12 @@ size_t median_scratch_bytes(unsigned long long count) {
 //   sampler(sample, s): fills s sample values (device);  sweep(consume): streams the whole population once through
 //   consume(data, cols, row0, rows) (row0: global row of the first row for the diagonal skip, or kNoDiagonalRow).
 // One host synchronisation (the bracket's verdict) when the one-sweep path is taken.
+// stat_part / stat_pivot / stat_nparts (optional): the one-sweep path leaves statistic partials of the population there (one per
+// workgroup of every sweep launch, *stat_nparts of them); *stat_nparts stays 0 when the sweep did not run.
 int lower_median_of(unsigned long long count, const MedianSampler& sampler, const MedianSweep& sweep, float* out, void* scratch,
-                    hipStream_t s) {
+                    hipStream_t s, void* stat_part, const float* stat_pivot, int64_t* stat_nparts) {
+  if (stat_nparts) *stat_nparts = 0;
+  int64_t parts_used = 0;
   char* base = static_cast<char*>(scratch);
   BracketState* st = reinterpret_cast<BracketState*>(base);
   float* sample = reinterpret_cast<float*>(base + bracket_state_bytes());
@@ -435,11 +471,15 @@ int lower_median_of(unsigned long long count, const MedianSampler& sampler, cons
     MMF_TRY(sweep([&](const float* data, int64_t cols, int64_t row0, int64_t rows) -> int {
       if (rows <= 0) return MMF_OK;
       int64_t grid = (rows + 3) / 4;
-      if (grid > 2048) grid = 2048;
-      hipLaunchKernelGGL(bracket_sweep_kernel, dim3((unsigned)grid), dim3(256), 0, s, data, cols, row0, rows, st, buf);
+      if (grid > (stat_part ? 2040 : 2048)) grid = stat_part ? 2040 : 2048;     // a ragged last row adds one launch of one workgroup
+      StatPartial* sp = stat_part ? reinterpret_cast<StatPartial*>(stat_part) + parts_used : nullptr;
+      if (sp && parts_used + grid > 2048) { set_error("median sweep: more than 2048 statistic partials"); return MMF_E_INTERNAL; }
+      hipLaunchKernelGGL(bracket_sweep_kernel, dim3((unsigned)grid), dim3(256), 0, s, data, cols, row0, rows, st, buf, sp, stat_pivot);
       MMF_LAUNCH_CHECK();
+      if (sp) parts_used += grid;
       return MMF_OK;
     }));
+    if (stat_nparts) *stat_nparts = parts_used;
     hipLaunchKernelGGL(bracket_begin_kernel, dim3(1), dim3(64), 0, s, st);
     MMF_LAUNCH_CHECK();
     MedianState* sel = &st->sel;
@@ -501,14 +541,6 @@ int launch_lower_median(const float* v, int64_t count, float* out, void* scratch
 // every workgroup writes its partial, one workgroup merges them in index order.
 // Replaces: K.mean(), K.std(), K.min(), K.max() — four passes — at preprocess_hypergraph.py:190-195, 260-263.
 // ------------------------------------------------------------------------------------------------
-struct StatPartial { double s1, s2; float mn, mx; };
-
-__device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-  return x;
-}
-
 __global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restrict__ v, int64_t count, StatPartial* __restrict__ part) {
   const double p = (double)v[0];                       // pivot: sums of (x - p) stay small when the values cluster
   double s1 = 0.0, s2 = 0.0;
@@ -575,13 +607,20 @@ int launch_array_stats(const float* v, int64_t count, double* out, void* scratch
   char* rest = reinterpret_cast<char*>(scratch) + 2048 * sizeof(StatPartial);
   float* med = reinterpret_cast<float*>(rest);
   void* mscratch = rest + 256;
-  int64_t grid = (count + 256 * 16 - 1) / (256 * 16);
-  if (grid > 2048) grid = 2048;
-  if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(stats_partial_kernel, dim3((unsigned)grid), dim3(256), 0, s, v, count, part);
-  MMF_LAUNCH_CHECK();
-  MMF_TRY(launch_stats_finish(part, grid, v, count, out, s));
-  MMF_TRY(launch_lower_median(v, count, med, mscratch, s));
+  // large arrays: the median's one sweep also leaves the statistic partials (one read of the array instead of two)
+  int64_t nparts = 0;
+  MMF_TRY(lower_median_of(
+      (unsigned long long)count, [&](float* sample, int sc) { return launch_sample_gather(v, 0, (unsigned long long)count, sample, sc, s); },
+      [&](const MedianConsume& consume) { return sweep_flat(v, count, consume); }, med, mscratch, s, part, v, &nparts));
+  if (nparts == 0) {
+    int64_t grid = (count + 256 * 16 - 1) / (256 * 16);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(stats_partial_kernel, dim3((unsigned)grid), dim3(256), 0, s, v, count, part);
+    MMF_LAUNCH_CHECK();
+    nparts = grid;
+  }
+  MMF_TRY(launch_stats_finish(part, nparts, v, count, out, s));
   return launch_stats_set_median(med, out, s);
 }
 
@@ -647,7 +686,7 @@ __global__ __launch_bounds__(1024) void thr_scan_kernel(const uint32_t* __restri
   unsigned long long run = base + ((t == 0) ? 0ull : part[t - 1]);
   for (int64_t i = b; i < e; ++i) { row_off[i] = run; run += row_cnt[i]; }
   __syncthreads();                                   // everybody has read the base
-  if (t == 1023) *out_count = (int64_t)(base + part[1023]);
+  if (t == 1023) { *out_count = (int64_t)(base + part[1023]); row_off[n] = base + part[1023]; }
 }
 
 __global__ __launch_bounds__(256) void thr_fill_kernel(const float* __restrict__ K, int64_t n, int64_t row0, int64_t rows,
@@ -713,6 +752,25 @@ int launch_threshold_edges(const float* K, int64_t n, float thr, int64_t* ei, fl
                            int64_t* out_count, uint32_t* scratch, size_t scratch_u32, hipStream_t s) {
   return launch_threshold_edges_panel(K, n, 0, n, thr, ei, ei ? ei + capacity : nullptr, ew, capacity, out_count, scratch,
                                       scratch_u32, s);
+}
+
+// The two halves of the above for a caller that sizes its outputs from the count: the counting pass leaves the rows'
+// exclusive offsets (row_off[n + 1], row_off[n] = total), the fill pass takes them — K is read twice, not three times.
+int launch_threshold_count(const float* K, int64_t n, float thr, unsigned long long* row_off, int64_t* out_count, uint32_t* row_cnt,
+                           hipStream_t s) {
+  const unsigned grid = (unsigned)((n + 3) / 4);
+  hipLaunchKernelGGL(thr_count_kernel, dim3(grid), dim3(256), 0, s, K, n, n, thr, row_cnt);
+  MMF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(thr_scan_kernel, dim3(1), dim3(1024), 0, s, row_cnt, n, row_off, out_count);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+int launch_threshold_fill(const float* K, int64_t n, float thr, const unsigned long long* row_off, int64_t* ei, float* ew,
+                          int64_t capacity, hipStream_t s) {
+  const unsigned grid = (unsigned)((n + 3) / 4);
+  hipLaunchKernelGGL(thr_fill_kernel, dim3(grid), dim3(256), 0, s, K, n, (int64_t)0, n, thr, row_off, ei, ei + capacity, ew, capacity);
+  MMF_LAUNCH_CHECK();
+  return MMF_OK;
 }
 
 }  // namespace mmf

@@ -180,7 +180,7 @@ using MedianSampler = std::function<int(float* sample, int s)>;   // s values at
 size_t median_scratch_bytes(unsigned long long count);
 int64_t median_no_diagonal_row();                                  // row0 for data without a diagonal to skip
 int lower_median_of(unsigned long long count, const MedianSampler& sampler, const MedianSweep& sweep, float* out, void* scratch,
-                    hipStream_t s);
+                    hipStream_t s, void* stat_part = nullptr, const float* stat_pivot = nullptr, int64_t* stat_nparts = nullptr);
 int launch_sample_gather(const float* data, int64_t n_sq, unsigned long long count, float* sample, int s_count, hipStream_t s);
 int launch_sample_pairs(const void* A, const void* B, int64_t nb, int64_t d, int dtype, float lambda, const float* P, int dp,
                         float lambda_g, int offdiag, unsigned long long count, float* sample, int s_count, hipStream_t s);
@@ -208,6 +208,11 @@ int launch_threshold_edges_panel(const float* K, int64_t n, int64_t row0, int64_
 int launch_threshold_edges(const float* K, int64_t n, float thr, int64_t* ei, float* ew,
                            int64_t capacity, int64_t* out_count, uint32_t* scratch, size_t scratch_u32,
                            hipStream_t s);
+
+int launch_threshold_count(const float* K, int64_t n, float thr, unsigned long long* row_off, int64_t* out_count, uint32_t* row_cnt,
+                           hipStream_t s);
+int launch_threshold_fill(const float* K, int64_t n, float thr, const unsigned long long* row_off, int64_t* ei, float* ew,
+                          int64_t capacity, hipStream_t s);
 
 // mmf_segments.hip: cluster-shaped steps (labels -> members, per-cluster means, cliques, k-NN pair dedup)
 int segment_max_segments();

@@ -209,14 +209,15 @@ def threshold_edges(K: torch.Tensor, threshold: float) -> Tuple[torch.Tensor, to
     cnt = torch.zeros((), dtype=torch.int64, device=K.device)
     L = _lib.lib()
     dev, st = K.device.index or 0, _stream(K.device)
-    # pass 1: count only (capacity 0); pass 2: fill exactly
-    _lib.check(L.mmf_threshold_edges(_p(K), n, float(threshold), None, None, 0, _p(cnt), dev, st), "mmf_threshold_edges")
+    # pass 1: count + row offsets; pass 2: fill from the offsets (K is read twice in all)
+    row_off = torch.empty((n + 1,), dtype=torch.int64, device=K.device)
+    _lib.check(L.mmf_threshold_edges_count(_p(K), n, float(threshold), _p(row_off), _p(cnt), dev, st), "mmf_threshold_edges_count")
     E = int(cnt.item())
     ei = torch.empty((2, E), dtype=torch.int64, device=K.device)
     ew = torch.empty((E,), dtype=torch.float32, device=K.device)
     if E:
-        _lib.check(L.mmf_threshold_edges(_p(K), n, float(threshold), _p(ei), _p(ew), E, _p(cnt), dev, st),
-                   "mmf_threshold_edges")
+        _lib.check(L.mmf_threshold_edges_fill(_p(K), n, float(threshold), _p(row_off), _p(ei), _p(ew), E, dev, st),
+                   "mmf_threshold_edges_fill")
     return ei, ew
 
 
