@@ -36,6 +36,8 @@ struct SelectArgs {
   // other's candidate rows in that XCD's L2 instead of gathering them from HBM again.
   uint32_t* key_in; uint32_t* row_in;              // pass 0 writes
   const uint32_t* key_sorted; const uint32_t* row_sorted;   // pass 1 reads
+  uint8_t* done;                                   // [n_rows] rows the grouped re-rank (rerank_group_kernel) has finished
+  int64_t order_blocks;                            // staged kernel: virtual blocks of SEL_WAVES rows the launch walks (grid-stride)
   int64_t* out_idx; float* out_val;
   int32_t* fail_rows; uint32_t* fail_count; uint32_t* cand_total;
   int maxc;   // staged kernel: candidate slots per wave in dynamic LDS
@@ -284,15 +286,19 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
   float (*xtile)[SC] = reinterpret_cast<float (*)[SC]>(sel_smem + sizeof(float) * SEL_WAVES * SG * SLD);
   float* skey_base = reinterpret_cast<float*>(sel_smem + sizeof(float) * SEL_WAVES * (SG * SLD + SC));
   uint32_t* sid_base = reinterpret_cast<uint32_t*>(skey_base + SEL_WAVES * maxc);
-  int64_t pos = (int64_t)blockIdx.x * SEL_WAVES + wave;
+  // The ordered second pass walks its (virtual) blocks with a grid-stride loop: behind the grouped re-rank almost every row is
+  // already done, and 65536 workgroups that only look at a flag cost 1.5 ms in workgroup launches alone.
+  for (int64_t vb = blockIdx.x; vb < a.order_blocks; vb += gridDim.x) {
+  int64_t pos = vb * SEL_WAVES + wave;
   if (a.pass == 1 && a.key_sorted) {
-    // block b -> chunk (b % 8) * (blocks / 8) + b / 8 of the sorted order (the grid is a multiple of 8 blocks)
-    const int64_t per = gridDim.x >> 3;
-    const int64_t slot = (((int64_t)blockIdx.x & 7) * per + ((int64_t)blockIdx.x >> 3)) * SEL_WAVES + wave;
-    if (slot >= a.n_rows || a.key_sorted[slot] == 0xffffffffu) return;
+    // virtual block b -> chunk (b % 8) * (blocks / 8) + b / 8 of the sorted order (order_blocks is a multiple of 8)
+    const int64_t per = a.order_blocks >> 3;
+    const int64_t slot = ((vb & 7) * per + (vb >> 3)) * SEL_WAVES + wave;
+    if (slot >= a.n_rows || a.key_sorted[slot] == 0xffffffffu) continue;
     pos = (int64_t)a.row_sorted[slot];
+    if (a.done && a.done[pos]) continue;
   } else {
-    if (pos >= a.n_rows) return;
+    if (pos >= a.n_rows) continue;
     if (a.two_pass) {
       // two passes: rows with overflow entries wait for the second launch, which has LDS room for them.  Both launches
       // cover every row and a row decides by its own counters which one it belongs to (a queue filled through one
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
         }
         if (lane == 0) { a.key_in[pos] = mn; a.row_in[pos] = (uint32_t)pos; }
       }
-      if (deferred != (a.pass == 1)) return;
+      if (deferred != (a.pass == 1)) continue;
     }
   }
   const int64_t row = a.row_ids ? (int64_t)a.row_ids[pos] : pos;
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
       a.fail_rows[slot] = (int32_t)pos;
       atomicAdd(a.fail_count + (was_overflow ? 1 : 2), 1u);
     }
-    return;
+    continue;
   }
   if (a.cand_total && lane == 0) atomicAdd(a.cand_total + (blockIdx.x & 255), (uint32_t)total);
   __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -439,6 +445,215 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
   }
+  }   // virtual blocks
+}
+
+// ------------------------------------------------------------------------------------------------
+// Grouped re-rank of the rows that wait for the second pass (near-duplicate data: a row's margin band is its whole cluster,
+// 129 candidates per row at the benchmark's clustered workload).  In key order — smallest candidate id — 32 consecutive rows
+// mostly share one candidate set, so a workgroup takes 32 such rows, forms the UNION of their candidates (an LDS hash table:
+// id -> panel column), and computes all 32 x |union| canonical dots on the matrix cores: v_mfma_f32_32x32x2_f32 accumulates
+// exactly the k-ordered fmaf chain (products commute), so the keys are the bits the per-row chains produce.
+// Each row then looks its own candidates up and selects as before.  Candidate rows are gathered once per 32 queries instead
+// of once per query, and no lane walks a 512-long chain out of LDS.  A group whose union exceeds GR_PMAX columns (or a row
+// the lists could not serve) is left to the per-row pass behind this kernel (a.done stays 0).
+// ------------------------------------------------------------------------------------------------
+constexpr int GR_Q = 32, GR_PMAX = 384, GR_KC = 16, GR_MAXC = 224, GR_HASH = 1024, GR_LD = GR_KC + 1, GR_W = 8;
+struct GroupLds {
+  uint32_t cid[GR_Q][GR_MAXC];
+  float ckey[GR_Q][GR_MAXC];
+  float dots[GR_Q][GR_PMAX + 1];
+  float qtile[2][GR_Q][GR_LD];
+  float ptile[2][GR_W][32][GR_LD];
+  uint32_t hkey[GR_HASH];
+  uint32_t hval[GR_HASH];
+  uint32_t panel[GR_PMAX];
+  int qpos[GR_Q];
+  int qtot[GR_Q];
+  int np;
+  int fail;
+};
+
+template <int METRIC, int DT>
+__global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char grp_smem[];
+  GroupLds& L = *reinterpret_cast<GroupLds*>(grp_smem);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // block b -> group (b % 8) * (groups / 8) + b / 8 of the sorted order: an XCD walks a contiguous eighth of it
+  const int64_t per = gridDim.x >> 3;
+  const int64_t grp = ((int64_t)blockIdx.x & 7) * per + ((int64_t)blockIdx.x >> 3);
+  const int64_t slot0 = grp * GR_Q;
+  if (slot0 >= a.n_rows) return;
+  if (tid < GR_Q) {
+    const int64_t slot = slot0 + tid;
+    int p = -1;
+    if (slot < a.n_rows && a.key_sorted[slot] != 0xffffffffu) p = (int)a.row_sorted[slot];
+    L.qpos[tid] = p;
+    L.qtot[tid] = -1;
+  }
+  for (int i = tid; i < GR_HASH; i += 64 * GR_W) L.hkey[i] = 0xffffffffu;
+  if (tid == 0) { L.np = 0; L.fail = 0; }
+  __syncthreads();
+  if (L.qpos[0] < 0) return;                        // sorted order: nothing waits from here on
+  // (1) the rows' candidate lists (pruned by the union of their lists as in the per-row pass)
+  for (int qq = 0; qq < GR_Q / GR_W; ++qq) {
+    const int q = (GR_Q / GR_W) * w + qq;
+    const int pos = L.qpos[q];
+    if (pos < 0) continue;
+    int total = -1;
+    if (a.overflow[pos] == 0) total = gather_candidates(a, pos, lane, L.cid[q], L.ckey[q], GR_MAXC);
+    if (lane == 0) L.qtot[q] = total;
+  }
+  __syncthreads();
+  // (2) union of the candidates: id -> panel column
+  for (int q = 0; q < GR_Q; ++q) {
+    const int total = L.qtot[q];
+    for (int e = tid; e < total; e += 64 * GR_W) {
+      const uint32_t id = L.cid[q][e];
+      if ((int64_t)id >= a.m) continue;
+      uint32_t h = (id * 2654435761u) >> 22;
+      for (int probe = 0; probe < GR_HASH; ++probe) {
+        if (*(volatile int*)&L.fail) break;
+        const uint32_t prev = atomicCAS(&L.hkey[h], 0xffffffffu, id);
+        if (prev == 0xffffffffu) {
+          const int idx = atomicAdd(&L.np, 1);
+          if (idx < GR_PMAX) { L.panel[idx] = id; L.hval[h] = (uint32_t)idx; } else L.fail = 1;
+          break;
+        }
+        if (prev == id) break;
+        h = (h + 1) & (GR_HASH - 1);
+      }
+    }
+  }
+  __syncthreads();
+  if (L.fail) return;
+  const int np = L.np;
+  // (3) all 32 x np canonical dots: in pass p wave w owns panel columns [256 p + 32 w, + 32)
+  for (int pass = 0; pass * 32 * GR_W < np; ++pass) {
+    const int64_t d = a.d;
+    const int nchunk = (int)((d + GR_KC - 1) / GR_KC);
+    const bool qstage = tid < 128;                                    // query tile: 32 rows x 16 k = 128 16-byte pieces
+    const int sq_row = (tid >> 2) & 31, sq_k = (tid & 3) * 4;
+    const int64_t qrow = L.qpos[sq_row] >= 0 ? (int64_t)L.qpos[sq_row] : (int64_t)L.qpos[0];
+    const int c0 = pass * 32 * GR_W + 32 * w;
+    const bool active = c0 < np;                                      // waves beyond the panel only keep the barriers
+    int64_t prow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = c0 + (lane >> 2) + 16 * i;
+      prow[i] = (int64_t)L.panel[c < np ? c : 0];
+    }
+    const int pk = (lane & 3) * 4;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    f32x4 qv = {0.f, 0.f, 0.f, 0.f}, pv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    auto gload = [&](int ch) {
+      const int64_t k0 = (int64_t)ch * GR_KC;
+      if (qstage) {
+        qv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (k0 + sq_k < d) qv = ld4_row<DT>(a.X, qrow * d + k0 + sq_k);
+      }
+      if (active) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          pv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (k0 + pk < d) pv[i] = ld4_row<DT>(a.Y, prow[i] * d + k0 + pk);
+        }
+      }
+    };
+    auto swrite = [&](int buf) {
+      if (qstage) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) L.qtile[buf][sq_row][sq_k + e] = qv[e];
+      }
+      if (active) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) L.ptile[buf][w][(lane >> 2) + 16 * i][pk + e] = pv[i][e];
+      }
+    };
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int buf = ch & 1;
+      if (ch + 1 < nchunk) gload(ch + 1);
+      if (active) {
+        const float* qa = &L.qtile[buf][lane & 31][lane >> 5];
+        const float* pb = &L.ptile[buf][w][lane & 31][lane >> 5];
+#pragma unroll
+        for (int sx = 0; sx < GR_KC / 2; ++sx) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * sx], pb[2 * sx], acc, 0, 0, 0);
+      }
+      if (ch + 1 < nchunk) swrite(buf ^ 1);
+      __syncthreads();
+    }
+    // C layout: column (candidate) = lane & 31, row (query) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (c0 + (lane & 31) < GR_PMAX) L.dots[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][c0 + (lane & 31)] = acc[r];
+    }
+  }
+  __syncthreads();
+  // (4) every row: keys of its own candidates out of the dots, then the top-k under (key desc, id asc)
+  for (int qq = 0; qq < GR_Q / GR_W; ++qq) {
+    const int q = (GR_Q / GR_W) * w + qq;
+    const int pos = L.qpos[q];
+    const int total = L.qtot[q];
+    if (pos < 0 || total < 0) continue;
+    uint32_t* id = L.cid[q];
+    float* key = L.ckey[q];
+    const int64_t grow = a.row_offset + pos;
+    const float ri = a.rx[pos];
+    int valid = 0;
+    for (int e = lane; e < total; e += 64) {
+      const uint32_t j = id[e];
+      float kx = kNegInf;
+      if ((int64_t)j < a.m && !(a.exclude_self && (a.col_offset + (int64_t)j == grow))) {
+        uint32_t h = (j * 2654435761u) >> 22;
+        while (L.hkey[h] != j) h = (h + 1) & (GR_HASH - 1);
+        kx = key_from_dot<METRIC>(L.dots[q][L.hval[h]], ri, a.cy[j], a.neg_lambda);
+        if (kx != kx) kx = kNegInf;
+        ++valid;
+      } else {
+        id[e] = kNoIdx;
+      }
+      key[e] = kx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) valid += __shfl_xor(valid, o);
+    if (valid < a.k) continue;                      // short of candidates: the per-row pass reports the row
+    if (a.cand_total && lane == 0) atomicAdd(a.cand_total + (blockIdx.x & 255), (uint32_t)total);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    for (int t = 0; t < a.k; ++t) {
+      float bk = kNegInf;
+      uint32_t bi = kNoIdx;
+      int be = -1;
+      for (int e = lane; e < total; e += 64) {
+        const uint32_t ie = id[e];
+        if (ie != kNoIdx && (be < 0 || better(key[e], ie, bk, bi))) { bk = key[e]; bi = ie; be = e; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ok2 = __shfl_xor(bk, o);
+        const uint32_t oi = (uint32_t)__shfl_xor((int)bi, o);
+        const int oe = __shfl_xor(be, o);
+        const bool take = (oe >= 0) && (be < 0 || better(ok2, oi, bk, bi));
+        if (take) { bk = ok2; bi = oi; be = oe; }
+      }
+      if (be >= 0 && (be & 63) == lane) id[be] = kNoIdx;
+      if (lane == 0) {
+        a.out_idx[(int64_t)pos * a.k + t] = a.col_offset + (int64_t)bi;
+        a.out_val[(int64_t)pos * a.k + t] = val_from_key<METRIC>(bk);
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) a.done[pos] = 1;
+  }
 }
 
 template <int METRIC>
@@ -463,13 +678,29 @@ static int launch_select_m(const SelectArgs& a, bool vec4, bool staged16, void* 
       const size_t lds = sizeof(float) * SEL_WAVES * (sg * SLD + SC) + (size_t)SEL_WAVES * b.maxc * 8;
       MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       int64_t g = grid;
+      b.order_blocks = grid;
       if (pass == 1 && a.key_in) {                    // order the waiting rows by their smallest candidate id
         size_t tb = order_temp_bytes;
         MMF_HIP(hipcub::DeviceRadixSort::SortPairs(order_temp, tb, a.key_in, const_cast<uint32_t*>(a.key_sorted), a.row_in,
                                                    const_cast<uint32_t*>(a.row_sorted), (int)a.n_rows, 0, 32, s));
         g = (grid + 7) / 8 * 8;
+        b.order_blocks = g;
+        // grouped re-rank of 32 consecutive rows of that order on the matrix cores; what it leaves is done by the launch below
+        if (a.done && (vec4 || staged16) && a.lists * a.cap + a.spill_cap <= GR_MAXC && !getenv("MMF_SELECT_NO_GROUPS")) {
+          MMF_HIP(hipMemsetAsync(a.done, 0, (size_t)a.n_rows, s));
+          auto gk = a.dtype == MMF_F32 ? rerank_group_kernel<METRIC, MMF_F32>
+                    : (a.dtype == MMF_BF16 ? rerank_group_kernel<METRIC, MMF_BF16> : rerank_group_kernel<METRIC, MMF_F16>);
+          MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GroupLds)));
+          const int64_t groups = ((a.n_rows + GR_Q - 1) / GR_Q + 7) / 8 * 8;
+          hipLaunchKernelGGL(gk, dim3((unsigned)groups), dim3(64 * GR_W), sizeof(GroupLds), s, b);
+          MMF_LAUNCH_CHECK();
+          if (g > 2048) g = 2048;                     // what is left: few rows, walked by a grid-stride loop
+        } else {
+          b.done = nullptr;
+        }
       } else if (pass == 1) {
         b.key_sorted = nullptr;
+        b.done = nullptr;
       }
       hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(64 * SEL_WAVES), lds, s, b);
       MMF_LAUNCH_CHECK();
@@ -480,13 +711,13 @@ static int launch_select_m(const SelectArgs& a, bool vec4, bool staged16, void* 
   return MMF_OK;
 }
 
-// scratch of the ordered second pass: four u32 arrays of n (rounded to 64) + the radix sort's temporary storage
+// scratch of the ordered second pass: four u32 arrays of n (rounded to 64), the done flags, the radix sort's temporary storage
 size_t select_order_bytes(int64_t n) {
   const size_t nn = ((size_t)n + 63) & ~size_t(63);
   size_t tb = 0;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                                            (int)n, 0, 32, (hipStream_t)0);
-  return 4 * nn * 4 + ((tb + 255) & ~size_t(255)) + 256;
+  return 5 * nn * 4 + ((tb + 255) & ~size_t(255)) + 256;
 }
 
 int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
@@ -510,8 +741,9 @@ int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
     uint32_t* o = static_cast<uint32_t*>(p.order_scratch);
     const size_t nn = ((size_t)p.n_rows + 63) & ~size_t(63);
     a.key_in = o; a.row_in = o + nn; a.key_sorted = o + 2 * nn; a.row_sorted = o + 3 * nn;
-    order_temp = o + 4 * nn;
-    order_temp_bytes = select_order_bytes(p.n_rows) - 4 * nn * 4;
+    a.done = reinterpret_cast<uint8_t*>(o + 4 * nn);
+    order_temp = o + 5 * nn;
+    order_temp_bytes = select_order_bytes(p.n_rows) - 5 * nn * 4;
   }
   a.out_idx = p.out_idx; a.out_val = p.out_val;
   a.fail_rows = p.fail_rows; a.fail_count = p.fail_count; a.cand_total = p.cand_total;
