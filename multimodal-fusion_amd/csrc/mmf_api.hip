@@ -59,7 +59,7 @@ int launch_edge_cosine_impl(const void* X, int64_t d, int dtype, const float* nr
 
 // mmf_scan_bf16.hip (fast path)
 int scan_bf16_supported(int64_t d, int kk, int dtype);
-int scan_bf16_cap(int kk);
+int scan_bf16_cap(int kk, int dp);
 int scan_bf16_dp(int64_t d);
 int launch_prep_half(const void* X, int64_t n, int64_t d, int dtype, int metric, const float* scal,
                      const uint32_t* max_n, void* Z,
@@ -187,7 +187,7 @@ struct FastTail {
   FastTail(int64_t n_, int64_t m_, int kk_, int cap_, int forced_splits, int dp_, int panels_ = 1, int64_t m_panel_min = -1,
            int64_t m_panel_max = -1)
       : n(n_), m(m_), kk(kk_), cap(cap_), dp(dp_), panels(panels_) {
-    bcap = scan_bf16_cap(kk);
+    bcap = scan_bf16_cap(kk, dp);
     const int qt = scan_b16_queries_per_block(dp);
     if (m_panel_min < 0) m_panel_min = m;
     const int64_t row_blocks = (n + qt - 1) / qt, col_tiles = ((m_panel_min + 255) / 256 * 256) / 32;

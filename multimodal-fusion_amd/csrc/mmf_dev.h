@@ -314,7 +314,7 @@ struct SlotList {
 #pragma unroll
     for (int e = 0; e < 16; ++e) pr[e] = __shfl_xor(k[15 - e], 32);
     float c[16];
-    const bool low = (CAP == 16) && (kk > 16);     // k + self in 17..20: the threshold sits in the lower half
+    const bool low = (CAP >= 15) && (kk > 16);     // k + self in 17..20: the threshold sits in the lower half
 #pragma unroll
     for (int e = 0; e < 16; ++e) c[e] = low ? fminf(k[e], pr[e]) : fmaxf(k[e], pr[e]);
 #pragma unroll

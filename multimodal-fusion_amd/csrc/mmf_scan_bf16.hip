@@ -690,7 +690,7 @@ static int pad_dp(int64_t d) {
   if (d <= 1024) return 1024;
   return 0;
 }
-static int waves_for_dp(int dp) { return dp <= 512 ? 8 : 4; }   // workgroup shape of the kernel variant
+static int waves_for_dp(int dp) { return dp <= 512 ? 8 : 4; }   // waves that own queries (d <= 1024: four split-k pairs)
 
 int scan_bf16_supported(int64_t d, int kk, int dtype) {
   (void)dtype;
@@ -700,7 +700,13 @@ int scan_bf16_supported(int64_t d, int kk, int dtype) {
   return (kk <= 44 && dp <= 512) ? 1 : 0;          // two 32-entry lists (their 64 KiB do not fit beside 64 KiB tiles: d <= 512)
 }
 
-int scan_bf16_cap(int kk) { return kk <= B_CAP - 4 ? B_CAP : (kk <= 20 ? B_CAP_BIG : B_CAP_WIDE); }
+// d <= 1024 keeps the 15-entry lists up to k + self = 20: the split-k pair kernel has no LDS for 16-entry lists beside its
+// exchange block, and the one-wave-per-SIMD kernel that had (380-395 VGPRs, 7-17 of them spilled) is retired.  Two 15-entry
+// lists hold 13 each after a compaction: enough for the k-th best of their union; the surplus goes to the overflow list.
+int scan_bf16_cap(int kk, int dp) {
+  if (dp > 512) return B_CAP;
+  return kk <= B_CAP - 4 ? B_CAP : (kk <= 20 ? B_CAP_BIG : B_CAP_WIDE);
+}
 int scan_bf16_slot_ulp(int cap) { return cap <= 16 ? 16 : 32; }
 int scan_bf16_dp(int64_t d) { return pad_dp(d); }
 
@@ -824,10 +830,7 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
     case 128: rc = big ? launch_b16_t<8, 8, 2, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<8, 8, 4, B_CAP>(a, f16, grid, s); break;
     case 256: rc = big ? launch_b16_t<16, 8, 2, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<16, 8, 4, B_CAP>(a, f16, grid, s); break;
     case 512: rc = big ? launch_b16_t<32, 8, 1, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<32, 8, 2, B_CAP>(a, f16, grid, s); break;
-    case 1024:
-      if (big || getenv("MMF_SCAN_NO_SPLITK")) rc = big ? launch_b16_t<64, 4, 1, B_CAP_BIG>(a, f16, grid, s) : launch_b16_t<64, 4, 1, B_CAP>(a, f16, grid, s);
-      else rc = launch_b16_t<64, 8, 1, B_CAP, true>(a, f16, grid, s);
-      break;
+    case 1024: rc = launch_b16_t<64, 8, 1, B_CAP, true>(a, f16, grid, s); break;
     default: set_error("scan_b16: unsupported padded dim %d", dp);
   }
   if (rc == MMF_OK && (a.debug & 16)) {

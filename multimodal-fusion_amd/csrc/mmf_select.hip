@@ -37,6 +37,7 @@ struct SelectArgs {
   uint32_t* key_in; uint32_t* row_in;              // pass 0 writes
   const uint32_t* key_sorted; const uint32_t* row_sorted;   // pass 1 reads
   uint8_t* done;                                   // [n_rows] rows the grouped re-rank (rerank_group_kernel) has finished
+  uint32_t* defer_cnt;                             // [256] rows that wait for the second pass, counted by pass 0 (spread over 256 words)
   int64_t order_blocks;                            // staged kernel: virtual blocks of SEL_WAVES rows the launch walks (grid-stride)
   int64_t* out_idx; float* out_val;
   int32_t* fail_rows; uint32_t* fail_count; uint32_t* cand_total;
@@ -318,7 +319,10 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
           for (int o = 32; o > 0; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)mn, o); mn = v < mn ? v : mn; }
           if (mn == 0xffffffffu) mn = 0xfffffffeu;     // a waiting row always carries a key below the "not waiting" marker
         }
-        if (lane == 0) { a.key_in[pos] = mn; a.row_in[pos] = (uint32_t)pos; }
+        if (lane == 0) {
+          a.key_in[pos] = mn; a.row_in[pos] = (uint32_t)pos;
+          if (deferred) atomicAdd(a.defer_cnt + (blockIdx.x & 255), 1u);
+        }
       }
       if (deferred != (a.pass == 1)) continue;
     }
@@ -495,6 +499,16 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
   if (tid == 0) { L.np = 0; L.fail = 0; }
   __syncthreads();
   if (L.qpos[0] < 0) return;                        // sorted order: nothing waits from here on
+  // Grouping pays when the waiting rows are near-duplicates of each other — then (nearly) every row of the problem waits.  A few
+  // scattered rows with overflow entries (Gaussian rows under bf16 operands) share nothing: their unions overflow the panel and
+  // the time spent finding that out is lost, so below an eighth of the rows the per-row pass takes them all.
+  if (tid < 256) { const uint32_t v = a.defer_cnt[tid]; if (v) atomicAdd(&L.fail, (int)v); }
+  __syncthreads();
+  const bool few = (int64_t)L.fail * 8 < a.n_rows;
+  __syncthreads();
+  if (few) return;
+  if (tid == 0) L.fail = 0;
+  __syncthreads();
   // (1) the rows' candidate lists (pruned by the union of their lists as in the per-row pass)
   for (int qq = 0; qq < GR_Q / GR_W; ++qq) {
     const int q = (GR_Q / GR_W) * w + qq;
@@ -681,8 +695,11 @@ static int launch_select_m(const SelectArgs& a, bool vec4, bool staged16, void* 
       b.order_blocks = grid;
       if (pass == 1 && a.key_in) {                    // order the waiting rows by their smallest candidate id
         size_t tb = order_temp_bytes;
+        // keys are candidate ids < m, or 0xffffffff (not waiting): the low bits(m) + 1 bits order the ids and keep the marker last
+        int nb = 1;
+        while (nb < 32 && (int64_t(1) << (nb - 1)) < a.m) ++nb;
         MMF_HIP(hipcub::DeviceRadixSort::SortPairs(order_temp, tb, a.key_in, const_cast<uint32_t*>(a.key_sorted), a.row_in,
-                                                   const_cast<uint32_t*>(a.row_sorted), (int)a.n_rows, 0, 32, s));
+                                                   const_cast<uint32_t*>(a.row_sorted), (int)a.n_rows, 0, nb, s));
         g = (grid + 7) / 8 * 8;
         b.order_blocks = g;
         // grouped re-rank of 32 consecutive rows of that order on the matrix cores; what it leaves is done by the launch below
@@ -694,7 +711,7 @@ static int launch_select_m(const SelectArgs& a, bool vec4, bool staged16, void* 
           const int64_t groups = ((a.n_rows + GR_Q - 1) / GR_Q + 7) / 8 * 8;
           hipLaunchKernelGGL(gk, dim3((unsigned)groups), dim3(64 * GR_W), sizeof(GroupLds), s, b);
           MMF_LAUNCH_CHECK();
-          if (g > 2048) g = 2048;                     // what is left: few rows, walked by a grid-stride loop
+          if (g > 16384) g = 16384;                   // what is left, walked by a grid-stride loop
         } else {
           b.done = nullptr;
         }
@@ -717,7 +734,7 @@ size_t select_order_bytes(int64_t n) {
   size_t tb = 0;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                                            (int)n, 0, 32, (hipStream_t)0);
-  return 5 * nn * 4 + ((tb + 255) & ~size_t(255)) + 256;
+  return (5 * nn + 256) * 4 + ((tb + 255) & ~size_t(255)) + 256;
 }
 
 int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
@@ -742,8 +759,10 @@ int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
     const size_t nn = ((size_t)p.n_rows + 63) & ~size_t(63);
     a.key_in = o; a.row_in = o + nn; a.key_sorted = o + 2 * nn; a.row_sorted = o + 3 * nn;
     a.done = reinterpret_cast<uint8_t*>(o + 4 * nn);
-    order_temp = o + 5 * nn;
-    order_temp_bytes = select_order_bytes(p.n_rows) - 5 * nn * 4;
+    a.defer_cnt = o + 5 * nn;
+    order_temp = o + 5 * nn + 256;
+    order_temp_bytes = select_order_bytes(p.n_rows) - (5 * nn + 256) * 4;
+    MMF_HIP(hipMemsetAsync(a.defer_cnt, 0, 1024, s));
   }
   a.out_idx = p.out_idx; a.out_val = p.out_val;
   a.fail_rows = p.fail_rows; a.fail_count = p.fail_count; a.cand_total = p.cand_total;

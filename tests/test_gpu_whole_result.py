@@ -157,3 +157,11 @@ def test_column_range_above_4gib_splits_by_itself(mmf):
     assert st["precision_used"] == 2 and st["col_splits"] >= 2 and st["fallback_rows"] == 0, st
     ei, ev = mmf.simtopk(X, Y, metric="cosine", k=5, exclude_self=True, row_offset=1200000, precision="exact")
     assert torch.equal(fi, ei) and torch.equal(fv, ev)
+
+
+def test_d1024_k16_on_the_split_k_kernel_every_row(mmf):
+    """k + self = 17 at d = 1024: round 2 ran this on a one-wave-per-SIMD kernel that spilled registers; it now takes the split-k
+    pair kernel with 15-entry lists (threshold in the lower half of the pair's merged lists).  Every row against the exact scan."""
+    X = make(32768, 1024, 11).half()
+    whole_result(mmf, X, None, "cosine", 16, True, precisions=("fast",), oracle_rows=32)
+    whole_result(mmf, make(16384, 700, 12), None, "neg_sq_l2", 19, True, precisions=("fast",), oracle_rows=16)
