@@ -259,6 +259,7 @@ struct FastTail {
     L.spill_cnt = ws.take<uint32_t>(n);
     L.spill_ids = ws.take<uint32_t>((size_t)n * kSpillCap);
     L.spill_cap = kSpillCap;
+    L.spill_stacks = (lists == 2 && kSpillCap < 65536 && !getenv("MMF_SPILL_COUNTER")) ? 1 : 0;
     order_scratch = ws.take<char>(select_order_bytes(n));
   }
   int run(const void* X, int64_t n_, const void* Y, int64_t m_, int64_t d, int in_dtype, int metric, float lambda, int k,

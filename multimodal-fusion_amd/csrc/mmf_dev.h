@@ -227,9 +227,23 @@ struct SpillSink {
   // beyond cap fails, and the caller records the key as lost).
   static constexpr uint32_t kChunk = MMF_SINK_CHUNK, kEmpty = 0xffffffffu;
   uint32_t cpos = 0, cleft = 0;
+  // stacks != 0 — the row has ONE pair of lists (one launch, no column splits: exactly two lanes ever store for it): no counter
+  // at all.  The lower lane (stacks = 1) fills the row's slots from the front, the upper one (stacks = 2) from the back; each
+  // counts its own entries (cpos) and the pair writes both counts when the scan ends (low / high 16 bits of cnt[row]).  If the
+  // two stacks met — more than `cap` entries — the row is flagged for the exact rescan, as when the counter passed cap.  The
+  // returning atomics of the counter form (a round trip to the L2 the wave sits out once per eight entries) were 10 of the
+  // 72 ms of the scan on the clustered benchmark.
+  int stacks = 0;
   __device__ __forceinline__ bool put(uint32_t id, bool bulk) {
     if (cap == 0) return false;
     if (ablate) return true;
+    if (stacks) {
+      if (cpos >= cap) return false;
+      if (seg_len) id = (id / seg_len) * seg_stride + id % seg_len;
+      ids[row * cap + (stacks == 1 ? cpos : cap - 1u - cpos)] = id + id_off;
+      ++cpos;
+      return true;
+    }
     if (cleft == 0) {
       const uint32_t want = bulk ? kChunk : 1u;
       const uint32_t base = atomicAdd(cnt + row, want);
@@ -243,6 +257,7 @@ struct SpillSink {
     return true;
   }
   __device__ __forceinline__ void close() {
+    if (stacks) return;
     while (cleft != 0) { ids[row * cap + cpos] = kEmpty; ++cpos; --cleft; }
   }
 };

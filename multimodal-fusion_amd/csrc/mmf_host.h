@@ -99,6 +99,7 @@ struct CandLists {
   uint32_t* spill_cnt = nullptr;   // [n], zeroed before the first launch
   uint32_t* spill_ids = nullptr;   // [n][spill_cap], GLOBAL-mapped local column ids like `ids`
   int spill_cap = 0;
+  int spill_stacks = 0;            // lists == 2: the row's two lanes fill its slots from both ends; spill_cnt[row] = front | back << 16
 };
 
 // Where a launch of the 16-bit scan sits inside a paneled scan (all zero: the whole problem in one launch).

@@ -214,6 +214,7 @@ struct ScanB16Args {
   float* cand_keys;          // approximate keys of the entries (select prunes with them), or nullptr
   float* margin_out;         // [n_rows] the queries' error margins, written with cand_keys
   uint32_t* spill_cnt; uint32_t* spill_ids; int spill_cap;   // per-row overflow lists (SpillSink), or nullptr / 0
+  int spill_stacks;          // one list pair per row: the two lanes fill the row's slots from both ends, no counter (SpillSink)
 };
 
 // Order-preserving float <-> int32 map (an involution) so that thresholds can be merged with atomicMax.
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
     list.sink.cnt = a.spill_cnt; list.sink.ids = a.spill_ids; list.sink.cap = (uint32_t)a.spill_cap; list.sink.row = qpos;
     list.sink.seg_len = a.seg_len; list.sink.seg_stride = a.seg_stride; list.sink.id_off = a.id_off;
     if (DBG) list.sink.ablate = (a.debug & 128) ? 1 : 0;
+    if (a.spill_stacks) list.sink.stacks = 1 + half;
   }
   // Thresholds are shared between the workgroups (and launches) that scan different columns for the same
   // queries: any list's threshold bounds the approximate key of every member of the final top-k, whatever
@@ -655,6 +657,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 1) void scan_b16x_kernel(S
 
   list.compact(a.kk, margin);
   list.sink.close();                    // reserved overflow-list slots this lane did not use
+  if (a.spill_stacks && a.spill_cnt) {  // two-stack overflow lists: both counts in one word; stacks that met cost the row its fast path
+    const uint32_t mine = qvalid ? list.sink.cpos : 0u;
+    const uint32_t theirs = (uint32_t)__shfl_xor((int)mine, 32);
+    if (mine + theirs > (uint32_t)a.spill_cap) list.lost = kFltMax;
+    if (qvalid && half == 0 && (mine | theirs)) a.spill_cnt[qpos] = mine | (theirs << 16);
+  }
   sync_seed();
   if (qvalid) {
     const int64_t lbase = qpos * a.lists_total + a.list_base + 2 * split + half;
@@ -812,6 +820,7 @@ int launch_scan_b16(const void* ZQ, const void* ZC, const float* cb, const float
   }
   a.cand_cnt = L.cnt; a.cand_ids = L.ids; a.overflow = L.overflow; a.cand_keys = L.keys; a.margin_out = L.margin;
   a.spill_cnt = L.spill_cnt; a.spill_ids = L.spill_ids; a.spill_cap = L.spill_cap;
+  a.spill_stacks = L.spill_stacks;
   const int64_t grid = scan_b16_grid(n_rows, col_splits, dp);
   a.lids = reinterpret_cast<uint32_t*>(scratch);
   if (grid_out) *grid_out = (int)grid;

@@ -27,6 +27,7 @@ struct SelectArgs {
   const float* cand_keys; const float* margin;      // optional: approximate keys of the entries + the row's error margin
   int slot_ulp;                                     // ... which carry this many ulps of id-slot bits
   const uint32_t* spill_cnt; const uint32_t* spill_ids; int spill_cap;   // optional: the row's overflow list
+  int spill_stacks;                                 // its two-stack form: spill_cnt[row] = front | back << 16 (SpillSink)
   // staged kernel, two passes when overflow lists exist: pass 0 handles the rows without overflow entries in a lean
   // LDS footprint and queues the others; pass 1 (room for the overflow entries) takes the queue
   int pass; int two_pass;
@@ -105,16 +106,18 @@ __device__ __forceinline__ int gather_candidates(const SelectArgs& a, int64_t po
   // The counter counts RESERVED slots (lanes reserve in chunks, SpillSink): it may pass the capacity — a reservation
   // that found no room recorded its key as lost, and the audit flags the row if that key mattered — and reserved slots a
   // lane did not use hold 0xffffffff.
-  int n_sp = 0;
+  int n_sp = 0, n_front = 0;
   if (a.spill_cnt) {
     const uint32_t c = a.spill_cnt[pos];
-    n_sp = (int)(c < (uint32_t)a.spill_cap ? c : (uint32_t)a.spill_cap);
+    if (a.spill_stacks) { n_front = (int)(c & 0xffffu); n_sp = n_front + (int)(c >> 16); if (n_sp > a.spill_cap) n_sp = a.spill_cap; }
+    else { n_sp = (int)(c < (uint32_t)a.spill_cap ? c : (uint32_t)a.spill_cap); n_front = n_sp; }
   }
   auto append_spill = [&](int at) -> int {
     if (at + n_sp > maxc) return -1;
     for (int e0 = 0; e0 < n_sp; e0 += 64) {
       const int e = e0 + lane;
-      const uint32_t v = (e < n_sp) ? a.spill_ids[pos * a.spill_cap + e] : 0xffffffffu;
+      // entry e: slot e of the front stack, or slot cap - 1 - (e - front) of the back stack
+      const uint32_t v = (e < n_sp) ? a.spill_ids[pos * a.spill_cap + (e < n_front ? e : a.spill_cap - 1 - (e - n_front))] : 0xffffffffu;
       const bool keep = v != 0xffffffffu;
       const unsigned long long mask = __ballot(keep);
       if (keep) id[at + __popcll(mask & ((1ull << lane) - 1ull))] = v;
@@ -313,8 +316,13 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
             for (uint32_t e = lane; e < cn; e += 64) { const uint32_t v = a.cand_ids[(pos * a.lists + l) * a.cap + e]; mn = v < mn ? v : mn; }
           }
           const uint32_t c = a.spill_cnt[pos];
-          const uint32_t nsp = c < (uint32_t)a.spill_cap ? c : (uint32_t)a.spill_cap;
-          for (uint32_t e = lane; e < nsp; e += 64) { const uint32_t v = a.spill_ids[pos * a.spill_cap + e]; mn = v < mn ? v : mn; }
+          uint32_t nfr, nsp;
+          if (a.spill_stacks) { nfr = c & 0xffffu; nsp = nfr + (c >> 16); if (nsp > (uint32_t)a.spill_cap) nsp = (uint32_t)a.spill_cap; }
+          else { nsp = c < (uint32_t)a.spill_cap ? c : (uint32_t)a.spill_cap; nfr = nsp; }
+          for (uint32_t e = lane; e < nsp; e += 64) {
+            const uint32_t v = a.spill_ids[pos * a.spill_cap + (e < nfr ? e : (uint32_t)a.spill_cap - 1u - (e - nfr))];
+            mn = v < mn ? v : mn;
+          }
 #pragma unroll
           for (int o = 32; o > 0; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)mn, o); mn = v < mn ? v : mn; }
           if (mn == 0xffffffffu) mn = 0xfffffffeu;     // a waiting row always carries a key below the "not waiting" marker
@@ -750,7 +758,7 @@ int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
   a.row_ids = p.row_ids; a.n_rows = p.n_rows;
   a.cand_cnt = L.cnt; a.cand_ids = L.ids; a.overflow = L.overflow; a.lists = L.lists; a.cap = L.cap;
   a.cand_keys = L.keys; a.margin = L.margin; a.slot_ulp = L.slot_ulp;
-  a.spill_cnt = L.spill_cnt; a.spill_ids = L.spill_ids; a.spill_cap = L.spill_cap;
+  a.spill_cnt = L.spill_cnt; a.spill_ids = L.spill_ids; a.spill_cap = L.spill_cap; a.spill_stacks = L.spill_stacks;
   a.pass = 0; a.two_pass = p.two_pass ? 1 : 0;
   void* order_temp = nullptr;
   size_t order_temp_bytes = 0;
