@@ -279,6 +279,44 @@ __device__ __forceinline__ f32x4 ld4_row(const void* base, int64_t elem) {
   }
 }
 
+// Sort keys of the ordered second pass, one wave per 64 rows: a row that waits for that pass (overflow-list entries, not flagged)
+// gets its smallest candidate id, every other row the marker 0xffffffff; the waiting rows are counted (spread over 256 words).
+// Kept out of the first pass's kernel, whose register count decides how many of its waves fit a SIMD.
+__global__ __launch_bounds__(256) void select_keys_kernel(SelectArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  const int64_t mine = r0 + lane;
+  bool deferred = false;
+  if (mine < a.n_rows) deferred = a.overflow[mine] == 0 && a.spill_cnt[mine] != 0;
+  unsigned long long todo = __ballot(deferred);
+  uint32_t key = 0xffffffffu;
+  const int nwait = __popcll(todo);
+  while (todo) {
+    const int src = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    const int64_t pos = r0 + src;
+    uint32_t mn = 0xffffffffu;
+    for (int l = 0; l < a.lists; ++l) {
+      const uint32_t cn = a.cand_cnt[pos * a.lists + l];
+      for (uint32_t e = lane; e < cn; e += 64) { const uint32_t v = a.cand_ids[(pos * a.lists + l) * a.cap + e]; mn = v < mn ? v : mn; }
+    }
+    const uint32_t c = a.spill_cnt[pos];
+    uint32_t nfr, nsp;
+    if (a.spill_stacks) { nfr = c & 0xffffu; nsp = nfr + (c >> 16); if (nsp > (uint32_t)a.spill_cap) nsp = (uint32_t)a.spill_cap; }
+    else { nsp = c < (uint32_t)a.spill_cap ? c : (uint32_t)a.spill_cap; nfr = nsp; }
+    for (uint32_t e = lane; e < nsp; e += 64) {
+      const uint32_t v = a.spill_ids[pos * a.spill_cap + (e < nfr ? e : (uint32_t)a.spill_cap - 1u - (e - nfr))];
+      mn = v < mn ? v : mn;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)mn, o); mn = v < mn ? v : mn; }
+    if (mn == 0xffffffffu) mn = 0xfffffffeu;       // a waiting row always carries a key below the "not waiting" marker
+    if (lane == src) key = mn;
+  }
+  if (mine < a.n_rows) { a.key_in[mine] = key; a.row_in[mine] = (uint32_t)mine; }
+  if (lane == 0 && nwait) atomicAdd(a.defer_cnt + (blockIdx.x & 255), (uint32_t)nwait);
+}
+
 template <int METRIC, int DT, int SG>
 __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArgs a) {
   // dynamic LDS: per wave [maxc] keys + [maxc] ids (maxc = lists * cap rounded up to 64), then the tiles
@@ -292,9 +330,10 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
   uint32_t* sid_base = reinterpret_cast<uint32_t*>(skey_base + SEL_WAVES * maxc);
   // The ordered second pass walks its (virtual) blocks with a grid-stride loop: behind the grouped re-rank almost every row is
   // already done, and 65536 workgroups that only look at a flag cost 1.5 ms in workgroup launches alone.
-  for (int64_t vb = blockIdx.x; vb < a.order_blocks; vb += gridDim.x) {
+  constexpr bool SECOND = SG != 8;          // SG = 8 is the lean first pass: one virtual block per workgroup, no order
+  for (int64_t vb = blockIdx.x; vb < (SECOND ? a.order_blocks : (int64_t)gridDim.x); vb += gridDim.x) {
   int64_t pos = vb * SEL_WAVES + wave;
-  if (a.pass == 1 && a.key_sorted) {
+  if (SECOND && a.pass == 1 && a.key_sorted) {
     // virtual block b -> chunk (b % 8) * (blocks / 8) + b / 8 of the sorted order (order_blocks is a multiple of 8)
     const int64_t per = a.order_blocks >> 3;
     const int64_t slot = ((vb & 7) * per + (vb >> 3)) * SEL_WAVES + wave;
@@ -308,30 +347,6 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
       // cover every row and a row decides by its own counters which one it belongs to (a queue filled through one
       // atomic counter cost 25 cycles per row at the L2 when every row has overflow entries, i.e. on clustered data).
       const bool deferred = a.overflow[pos] == 0 && a.spill_cnt[pos] != 0;
-      if (a.key_in && a.pass == 0) {
-        uint32_t mn = 0xffffffffu;
-        if (deferred) {
-          for (int l = 0; l < a.lists; ++l) {
-            const uint32_t cn = a.cand_cnt[pos * a.lists + l];
-            for (uint32_t e = lane; e < cn; e += 64) { const uint32_t v = a.cand_ids[(pos * a.lists + l) * a.cap + e]; mn = v < mn ? v : mn; }
-          }
-          const uint32_t c = a.spill_cnt[pos];
-          uint32_t nfr, nsp;
-          if (a.spill_stacks) { nfr = c & 0xffffu; nsp = nfr + (c >> 16); if (nsp > (uint32_t)a.spill_cap) nsp = (uint32_t)a.spill_cap; }
-          else { nsp = c < (uint32_t)a.spill_cap ? c : (uint32_t)a.spill_cap; nfr = nsp; }
-          for (uint32_t e = lane; e < nsp; e += 64) {
-            const uint32_t v = a.spill_ids[pos * a.spill_cap + (e < nfr ? e : (uint32_t)a.spill_cap - 1u - (e - nfr))];
-            mn = v < mn ? v : mn;
-          }
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)mn, o); mn = v < mn ? v : mn; }
-          if (mn == 0xffffffffu) mn = 0xfffffffeu;     // a waiting row always carries a key below the "not waiting" marker
-        }
-        if (lane == 0) {
-          a.key_in[pos] = mn; a.row_in[pos] = (uint32_t)pos;
-          if (deferred) atomicAdd(a.defer_cnt + (blockIdx.x & 255), 1u);
-        }
-      }
       if (deferred != (a.pass == 1)) continue;
     }
   }
@@ -702,6 +717,8 @@ static int launch_select_m(const SelectArgs& a, bool vec4, bool staged16, void* 
       int64_t g = grid;
       b.order_blocks = grid;
       if (pass == 1 && a.key_in) {                    // order the waiting rows by their smallest candidate id
+        hipLaunchKernelGGL(select_keys_kernel, dim3((unsigned)((a.n_rows + 255) / 256)), dim3(256), 0, s, a);
+        MMF_LAUNCH_CHECK();
         size_t tb = order_temp_bytes;
         // keys are candidate ids < m, or 0xffffffff (not waiting): the low bits(m) + 1 bits order the ids and keep the marker last
         int nb = 1;
