@@ -38,7 +38,9 @@ struct SelectArgs {
   uint32_t* key_in; uint32_t* row_in;              // pass 0 writes
   const uint32_t* key_sorted; const uint32_t* row_sorted;   // pass 1 reads
   uint8_t* done;                                   // [n_rows] rows the grouped re-rank (rerank_group_kernel) has finished
-  uint32_t* defer_cnt;                             // [256] rows that wait for the second pass, counted by pass 0 (spread over 256 words)
+  int only_if;                                     // second pass: 0 always; 1 / 2: only when the grouped kernel finished less / not less than half of the waiting rows
+  uint32_t* defer_cnt;                             // [512] rows that wait for the second pass (select_keys_kernel) and, behind them, rows the
+                                                   //       grouped kernel finished — each count spread over 256 words
   int64_t order_blocks;                            // staged kernel: virtual blocks of SEL_WAVES rows the launch walks (grid-stride)
   int64_t* out_idx; float* out_val;
   int32_t* fail_rows; uint32_t* fail_count; uint32_t* cand_total;
@@ -331,9 +333,18 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
   // The ordered second pass walks its (virtual) blocks with a grid-stride loop: behind the grouped re-rank almost every row is
   // already done, and 65536 workgroups that only look at a flag cost 1.5 ms in workgroup launches alone.
   constexpr bool SECOND = SG != 8;          // SG = 8 is the lean first pass: one virtual block per workgroup, no order
+  if (SECOND && a.only_if) {                 // the launch shaped for the other case leaves at once
+    uint32_t c = 0, dn = 0;
+    for (int i = lane; i < 256; i += 64) { c += a.defer_cnt[i]; dn += a.defer_cnt[256 + i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { c += (uint32_t)__shfl_xor((int)c, o); dn += (uint32_t)__shfl_xor((int)dn, o); }
+    const bool scattered = (int64_t)dn * 2 < (int64_t)c;     // the grouped kernel finished less than half of the waiting rows
+    if ((a.only_if == 1) != scattered) return;
+  }
   for (int64_t vb = blockIdx.x; vb < (SECOND ? a.order_blocks : (int64_t)gridDim.x); vb += gridDim.x) {
   int64_t pos = vb * SEL_WAVES + wave;
-  if (SECOND && a.pass == 1 && a.key_sorted) {
+  if (SECOND && a.pass == 1 && a.key_sorted && a.only_if != 1) {   // (the launch for scattered rows walks them in row order: their
+                                                                     //  candidate sets share nothing, and row order keeps the list reads streaming)
     // virtual block b -> chunk (b % 8) * (blocks / 8) + b / 8 of the sorted order (order_blocks is a multiple of 8)
     const int64_t per = a.order_blocks >> 3;
     const int64_t slot = ((vb & 7) * per + (vb >> 3)) * SEL_WAVES + wave;
@@ -348,6 +359,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
       // atomic counter cost 25 cycles per row at the L2 when every row has overflow entries, i.e. on clustered data).
       const bool deferred = a.overflow[pos] == 0 && a.spill_cnt[pos] != 0;
       if (deferred != (a.pass == 1)) continue;
+      if (SECOND && a.pass == 1 && a.done && a.done[pos]) continue;
     }
   }
   const int64_t row = a.row_ids ? (int64_t)a.row_ids[pos] : pos;
@@ -522,14 +534,18 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
   if (tid == 0) { L.np = 0; L.fail = 0; }
   __syncthreads();
   if (L.qpos[0] < 0) return;                        // sorted order: nothing waits from here on
-  // Grouping pays when the waiting rows are near-duplicates of each other — then (nearly) every row of the problem waits.  A few
-  // scattered rows with overflow entries (Gaussian rows under bf16 operands) share nothing: their unions overflow the panel and
-  // the time spent finding that out is lost, so below an eighth of the rows the per-row pass takes them all.
-  if (tid < 256) { const uint32_t v = a.defer_cnt[tid]; if (v) atomicAdd(&L.fail, (int)v); }
+  // Grouping pays when the rows of a group share their candidates — near-duplicate rows, which then carry the SAME key (the
+  // smallest id of their common candidate set), so a group holds a few runs of equal keys.  Scattered rows with overflow
+  // entries (Gaussian rows under bf16 operands) carry 32 different keys and share nothing: their union would overflow the
+  // panel, and finding that out costs more than the per-row pass.  A group with more than four runs of keys is left alone.
+  {
+    const bool change = tid > 0 && tid < GR_Q && L.qpos[tid] >= 0 && a.key_sorted[slot0 + tid] != a.key_sorted[slot0 + tid - 1];
+    if (tid < 64) { const int cnt = __popcll(__ballot(change)); if (tid == 0) L.fail = cnt; }
+  }
   __syncthreads();
-  const bool few = (int64_t)L.fail * 8 < a.n_rows;
+  const bool alone = L.fail > 3;
   __syncthreads();
-  if (few) return;
+  if (alone) return;
   if (tid == 0) L.fail = 0;
   __syncthreads();
   // (1) the rows' candidate lists (pruned by the union of their lists as in the per-row pass)
@@ -689,7 +705,7 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_wave_barrier();
     }
-    if (lane == 0) a.done[pos] = 1;
+    if (lane == 0) { a.done[pos] = 1; atomicAdd(a.defer_cnt + 256 + (blockIdx.x & 255), 1u); }
   }
 }
 
@@ -737,6 +753,20 @@ static int launch_select_m(const SelectArgs& a, bool vec4, bool staged16, void* 
           hipLaunchKernelGGL(gk, dim3((unsigned)groups), dim3(64 * GR_W), sizeof(GroupLds), s, b);
           MMF_LAUNCH_CHECK();
           if (g > 16384) g = 16384;                   // what is left, walked by a grid-stride loop
+          // Few waiting rows (the group kernel left them all: scattered rows with a few dozen candidates each) are best served by
+          // 16-candidate groups — half the LDS, twice the waves; many (near-duplicate data: the rows of groups whose union did not
+          // fit) by 32.  The host does not know which case it is: both shapes are launched, the wrong one leaves at once.
+          if (sg == 32) {
+            SelectArgs c = b;
+            c.only_if = 1;
+            auto k16 = a.dtype == MMF_F32 ? select_staged_kernel<METRIC, MMF_F32, 16>
+                       : (a.dtype == MMF_BF16 ? select_staged_kernel<METRIC, MMF_BF16, 16> : select_staged_kernel<METRIC, MMF_F16, 16>);
+            const size_t lds16 = sizeof(float) * SEL_WAVES * (16 * SLD + SC) + (size_t)SEL_WAVES * c.maxc * 8;
+            MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+            hipLaunchKernelGGL(k16, dim3((unsigned)g), dim3(64 * SEL_WAVES), lds16, s, c);
+            MMF_LAUNCH_CHECK();
+            b.only_if = 2;
+          }
         } else {
           b.done = nullptr;
         }
@@ -759,7 +789,7 @@ size_t select_order_bytes(int64_t n) {
   size_t tb = 0;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                                            (int)n, 0, 32, (hipStream_t)0);
-  return (5 * nn + 256) * 4 + ((tb + 255) & ~size_t(255)) + 256;
+  return (5 * nn + 512) * 4 + ((tb + 255) & ~size_t(255)) + 256;
 }
 
 int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
@@ -785,9 +815,9 @@ int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
     a.key_in = o; a.row_in = o + nn; a.key_sorted = o + 2 * nn; a.row_sorted = o + 3 * nn;
     a.done = reinterpret_cast<uint8_t*>(o + 4 * nn);
     a.defer_cnt = o + 5 * nn;
-    order_temp = o + 5 * nn + 256;
-    order_temp_bytes = select_order_bytes(p.n_rows) - (5 * nn + 256) * 4;
-    MMF_HIP(hipMemsetAsync(a.defer_cnt, 0, 1024, s));
+    order_temp = o + 5 * nn + 512;
+    order_temp_bytes = select_order_bytes(p.n_rows) - (5 * nn + 512) * 4;
+    MMF_HIP(hipMemsetAsync(a.defer_cnt, 0, 2048, s));
   }
   a.out_idx = p.out_idx; a.out_val = p.out_val;
   a.fail_rows = p.fail_rows; a.fail_count = p.fail_count; a.cand_total = p.cand_total;
