@@ -88,7 +88,8 @@ __global__ void km_colfin_kernel(const double* __restrict__ partial, int64_t nbl
 }
 
 // mean32[col] = (((x_0 + x_1) + x_2) + ... ) / float32(n): the float32 row-by-row accumulation numpy's X.mean(axis=0) performs
-// on a C-contiguous float32 matrix, so the centred data are scikit-learn's bit for bit.  A chain of n dependent adds per column is
+// on a C-contiguous float32 matrix with d >= 2 (for d = 1 the column is contiguous and numpy sums it pairwise: an ulp of
+// difference in the mean there), so the centred data are scikit-learn's bit for bit.  A chain of n dependent adds per column is
 // latency, not bandwidth: a workgroup owns 8 columns (d / 8 workgroups keep enough loads in flight), stages chunks of 512 rows
 // through LDS — all 256 threads load, the next chunk's loads are in flight while the chain runs — and 8 lanes walk the rows.
 constexpr int CM_COLS = 8, CM_ROWS = 512;

@@ -44,7 +44,8 @@ def _data(kind, n, d, rng):
 
 CASES = [("gauss", 4000, 64, 25), ("blobs", 4000, 64, 6), ("unit", 600, 128, 10), ("sim", 600, 64, 10), ("gauss", 1500, 16, 40),
          ("blobs", 1500, 64, 25), ("sim", 64, 64, 1), ("gauss", 40, 64, 3), ("blobs", 40, 16, 10), ("unit", 64, 33, 6),
-         ("sim", 1500, 16, 40), ("unit", 4000, 128, 10), ("blobs", 160, 16, 40), ("gauss", 257, 1000, 7)]
+         ("sim", 1500, 16, 40), ("unit", 4000, 128, 10), ("blobs", 160, 16, 40), ("gauss", 257, 1000, 7),
+         ("gauss", 12, 5, 12), ("gauss", 300, 1, 4), ("unit", 65, 2, 64), ("gauss", 1, 7, 1), ("blobs", 3000, 31, 100)]
 
 
 @pytest.mark.parametrize("kind,n,d,k", CASES)
@@ -68,7 +69,9 @@ def test_labels_are_sklearns(kind, n, d, k):
     for i in range(10):
         assert np.array_equal(seeds[i].cpu().numpy(), ri["per_init"][i]["seeds"]), f"restart {i}: seeding differs"
     assert info["best_init"] == ri["best_init"]
-    assert abs(info["inertia"] - ri["inertia"]) <= 1e-9 * ri["inertia"]
+    # d = 1: numpy sums a contiguous column pairwise, the device row by row — the column mean, hence the centred data, may differ
+    # by an ulp there (labels unaffected in every case tried); for d >= 2 both accumulate row by row and the data are identical
+    assert abs(info["inertia"] - ri["inertia"]) <= (1e-6 if d == 1 else 1e-9) * ri["inertia"]
     assert np.array_equal(lab, ref.labels_), (f"labels differ from scikit-learn's in {int((lab != ref.labels_).sum())} places "
                                               f"(inertia {info['inertia']} vs {ref.inertia_}; ambiguous seeding decisions: "
                                               f"{info['ambiguous_draws']} draws, {info['ambiguous_trials']} trials)")
