@@ -67,7 +67,8 @@ extern "C" {
  * (final keys are always the canonical f32 chain); the mode only picks which MFMA pipe scans
  * the N x M pairs. */
 #define MMF_PREC_AUTO  0  /* FAST when the 16-bit scan supports the shape (d <= 1024 and k + self <= 20, or
-                             d <= 512 and k + self <= 44), else EXACT (any d, k + self <= 44)         */
+                             d <= 512 and k + self <= 44), else EXACT (any d, any k: k + self > 44
+                             takes ceil(k / (44 - self)) passes, each ranked after the one before)  */
 #define MMF_PREC_EXACT 1  /* v_mfma_f32_32x32x2_f32 scan, canonical keys in-kernel           */
 #define MMF_PREC_FAST  2  /* f16 MFMA scan (rows scaled by an exact power of two) with a proven error
                              margin + exact f32 re-rank; columns inside a row's margin that do not fit its

@@ -473,8 +473,11 @@ int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d
     set_error("simtopk: MMF_PREC_FAST does not support d = %lld, k = %d (use AUTO or EXACT)", (long long)d, k);
     return MMF_E_UNSUPPORTED;
   }
-  const int cap = scan_f32_cap(kk);
-  if (cap == 0) { set_error("simtopk: k = %d is above the supported maximum (43 with self excluded, 44 without)", k); return MMF_E_UNSUPPORTED; }
+  // k + self beyond 44 (one pass of the exact scan): several passes, each offering only what ranks after the previous pass's
+  // last entry (scikit-learn's n_neighbors is uncapped, preprocess_hypergraph.py:379)
+  const int kk_pass = kk <= 44 ? kk : 44;
+  const int cap = scan_f32_cap(kk_pass);
+  if (cap == 0) { set_error("simtopk: no list capacity for k = %d (internal)", k); return MMF_E_INTERNAL; }
 
   if (precision != MMF_PREC_EXACT) {
     // ---- fast path: f16/bf16 MFMA scan -> exact re-rank -> exact rescan of overflowed rows -------
@@ -543,7 +546,7 @@ int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d
   const bool same = (Y == X) && (m == n);
   size_t need = ws_bytes(n, 4) + (same ? 0 : ws_bytes(m, 4)) + ws_bytes((size_t)n * lists, 4) +
                 ws_bytes((size_t)n * lists * cap, 4) + ws_bytes(n, 4) + ws_bytes(n, 4) + ws_bytes(4, 4) + ws_bytes(256, 4) +
-                ws_bytes(prep_f32_bytes(m, d), 1) + (same ? 0 : ws_bytes(prep_f32_bytes(n, d), 1));
+                ws_bytes(prep_f32_bytes(m, d), 1) + (same ? 0 : ws_bytes(prep_f32_bytes(n, d), 1)) + 2 * ws_bytes(n, 4);
   Workspace ws;
   MMF_TRY(get_workspace(device_id, s, need, &ws));
   float* rx = ws.take<float>(n);
@@ -572,23 +575,35 @@ int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d
   if (!same) MMF_TRY(launch_prep_f32(X, n, d, in_dtype, nullptr, Xp, s));
   MMF_TRY(t_prep.stop(s));
 
-  ScanProblem sp{};
-  sp.X = X; sp.n = n; sp.Y = Y; sp.m = m; sp.d = d; sp.dtype = in_dtype; sp.metric = metric; sp.lambda = lambda;
-  sp.Xp = Xp; sp.Yp = Yp;
-  sp.kk = kk; sp.rx = rx; sp.cy = cy; sp.row_ids = nullptr; sp.n_rows = n; sp.col_splits = splits;
+  float* floor_key = ws.take<float>(n);
+  uint32_t* floor_id = ws.take<uint32_t>(n);
+  const int self1 = exclude_self ? 1 : 0;
+  const int k_pass_max = 44 - self1;              // entries one pass can emit
   int grid = 0;
+  const bool one_pass = k <= k_pass_max;          // timers: scan and re-rank apart for one pass, the whole loop as "scan" otherwise
   MMF_TRY(t_scan.start(profile, s));
-  MMF_TRY(launch_scan_f32(sp, L, s, &grid));
-  MMF_TRY(t_scan.stop(s));
+  for (int done = 0; done < k; done += k_pass_max) {
+    const int kp = (k - done < k_pass_max) ? (k - done) : k_pass_max;
+    const bool more = done + kp < k;
+    ScanProblem sp{};
+    sp.X = X; sp.n = n; sp.Y = Y; sp.m = m; sp.d = d; sp.dtype = in_dtype; sp.metric = metric; sp.lambda = lambda;
+    sp.Xp = Xp; sp.Yp = Yp;
+    sp.kk = kp + self1; sp.rx = rx; sp.cy = cy; sp.row_ids = nullptr; sp.n_rows = n; sp.col_splits = splits;
+    if (done > 0) { sp.floor_key = floor_key; sp.floor_id = floor_id; }
+    MMF_TRY(launch_scan_f32(sp, L, s, &grid));
+    if (one_pass) { MMF_TRY(t_scan.stop(s)); MMF_TRY(t_sel.start(profile, s)); }
 
-  SelectProblem q{};
-  q.X = X; q.n = n; q.Y = Y; q.m = m; q.d = d; q.dtype = in_dtype; q.metric = metric; q.lambda = lambda;
-  q.k = k; q.exclude_self = exclude_self; q.row_offset = row_offset; q.col_offset = col_offset;
-  q.rx = rx; q.cy = cy; q.row_ids = nullptr; q.n_rows = n; q.out_idx = out_idx; q.out_val = out_val;
-  q.fail_rows = fail_rows; q.fail_count = fail_count; q.cand_total = stats ? cand_total : nullptr;
-  MMF_TRY(t_sel.start(profile, s));
-  MMF_TRY(launch_select(q, L, s));
-  MMF_TRY(t_sel.stop(s));
+    SelectProblem q{};
+    q.X = X; q.n = n; q.Y = Y; q.m = m; q.d = d; q.dtype = in_dtype; q.metric = metric; q.lambda = lambda;
+    q.k = kp; q.exclude_self = exclude_self; q.row_offset = row_offset; q.col_offset = col_offset;
+    q.rx = rx; q.cy = cy; q.row_ids = nullptr; q.n_rows = n; q.out_idx = out_idx; q.out_val = out_val;
+    q.out_stride = k; q.out_off = done;
+    if (more) { q.floor_key_out = floor_key; q.floor_id_out = floor_id; }
+    q.fail_rows = fail_rows; q.fail_count = fail_count; q.cand_total = stats ? cand_total : nullptr;
+    MMF_TRY(launch_select(q, L, s));
+  }
+  if (one_pass) { MMF_TRY(t_sel.stop(s)); }
+  else { MMF_TRY(t_scan.stop(s)); MMF_TRY(t_sel.start(profile, s)); MMF_TRY(t_sel.stop(s)); }
 
   uint32_t h_fail = 0;
   MMF_HIP(hipMemcpyAsync(&h_fail, fail_count, 4, hipMemcpyDeviceToHost, s));

@@ -133,6 +133,8 @@ struct ScanProblem {
   const int32_t* row_ids;         // optional: scan only these rows of X (fallback), else nullptr
   int64_t n_rows;                 // number of rows to scan (== n when row_ids == nullptr)
   int col_splits;
+  const float* floor_key = nullptr;     // exact scan only: per query, offer only what ranks strictly after (floor_key, floor_id)
+  const uint32_t* floor_id = nullptr;   //   in the total order — the later passes of a call with k + self > 44
 };
 
 // mmf_scan_f32.hip: exact scan on v_mfma_f32_32x32x2_f32 (any d, f32/bf16/f16 inputs).
@@ -149,6 +151,9 @@ struct SelectProblem {
   int32_t* fail_rows; uint32_t* fail_count;   // rows whose lists overflowed (or came up short)
   uint32_t* cand_total;                        // optional accumulated candidate count
   bool two_pass = false;   // rows with overflow-list entries are handled by a second launch that has LDS room for them
+  int out_stride = 0, out_off = 0;       // out_idx / out_val rows are out_stride wide (0: k) and this call fills columns out_off .. out_off + k
+  float* floor_key_out = nullptr;        // optional: key and LOCAL column id of the last entry emitted per row (the next pass's floor)
+  uint32_t* floor_id_out = nullptr;
   void* order_scratch = nullptr;   // select_order_bytes(n_rows): that second launch walks its rows ordered by their smallest candidate id
 };
 size_t select_order_bytes(int64_t n);

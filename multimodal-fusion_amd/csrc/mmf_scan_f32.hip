@@ -56,6 +56,9 @@ struct ScanF32Args {
   int col_splits;
   int64_t tiles_per_split;
   uint32_t* cand_cnt; uint32_t* cand_ids; uint32_t* overflow;
+  // k beyond one pass (k + self > 44): only columns that rank strictly AFTER (floor_key[q], floor_id[q]) in the total order
+  // (key desc, id asc) are offered — the last entry the previous pass emitted for the row (NULL: no floor)
+  const float* floor_key; const uint32_t* floor_id;
   // dense epilogue
   float* out;
   const float* P; int dp; float neg_lambda_g;
@@ -102,6 +105,9 @@ __global__ __launch_bounds__(F_NT, (MODE == MODE_DENSE || CAP <= 16) ? 2 : 1) vo
   const int64_t qrow = qvalid ? (a.row_ids ? (int64_t)a.row_ids[qpos] : qpos) : 0;
   const float ri = qvalid ? a.rx[qrow] : 1.0f;
   const int metric = a.metric;
+  const bool floored = (MODE == MODE_SCAN) && a.floor_key != nullptr;
+  const float fk = (floored && qvalid) ? a.floor_key[qpos] : 0.0f;
+  const uint32_t fid = (floored && qvalid) ? a.floor_id[qpos] : 0u;
 
   // DENSE: the 16 query rows this lane's accumulator elements belong to (fixed for the workgroup's lifetime)
   float rq16[16];
@@ -281,6 +287,14 @@ __global__ __launch_bounds__(F_NT, (MODE == MODE_DENSE || CAP <= 16) ? 2 : 1) vo
           key[r] = jv ? key[r] : kNegInf;
           acc[t][r] = 0.0f;
         }
+        if (floored) {                             // wave-uniform: a later pass of a large-k call
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const uint32_t j = (uint32_t)(cand0 + (r & 3) + 8 * (r >> 2) + 4 * half);
+            const bool after = (key[r] < fk) || (key[r] == fk && j > fid);
+            key[r] = after ? key[r] : kNegInf;
+          }
+        }
         if (__builtin_expect(__any(max16(key) >= list.thr), 0)) list.offer_tile(key, (uint32_t)cand0, half, a.kk);
       }
     }
@@ -343,6 +357,7 @@ int launch_scan_f32(const ScanProblem& p, const CandLists& L, hipStream_t s, int
   const int64_t total_tiles = (p.m + F_CT - 1) / F_CT;
   a.tiles_per_split = (total_tiles + p.col_splits - 1) / p.col_splits;
   a.cand_cnt = L.cnt; a.cand_ids = L.ids; a.overflow = L.overflow;
+  a.floor_key = p.floor_key; a.floor_id = p.floor_id;
   const int64_t grid = ((p.n_rows + F_QT - 1) / F_QT) * p.col_splits;
   if (grid_out) *grid_out = (int)grid;
   a.metric = p.metric;

@@ -43,6 +43,8 @@ struct SelectArgs {
                                                    //       grouped kernel finished — each count spread over 256 words
   int64_t order_blocks;                            // staged kernel: virtual blocks of SEL_WAVES rows the launch walks (grid-stride)
   int64_t* out_idx; float* out_val;
+  int out_stride, out_off;                         // row stride of the outputs and first column this call fills
+  float* floor_key_out; uint32_t* floor_id_out;    // optional: (key, local id) of the last entry emitted per row
   int32_t* fail_rows; uint32_t* fail_count; uint32_t* cand_total;
   int maxc;   // staged kernel: candidate slots per wave in dynamic LDS
 };
@@ -243,8 +245,9 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_kernel(SelectArgs a) {
     // every lane now agrees on (bk, bi, be); the owner retires the entry
     if (be >= 0 && (be & 63) == lane) id[be] = kNoIdx;
     if (lane == 0) {
-      a.out_idx[row * a.k + t] = a.col_offset + (int64_t)bi;
-      a.out_val[row * a.k + t] = val_from_key<METRIC>(bk);
+      a.out_idx[row * a.out_stride + a.out_off + t] = a.col_offset + (int64_t)bi;
+      a.out_val[row * a.out_stride + a.out_off + t] = val_from_key<METRIC>(bk);
+      if (a.floor_key_out && t == a.k - 1) { a.floor_key_out[pos] = bk; a.floor_id_out[pos] = bi; }
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -478,8 +481,9 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
     }
     if (be >= 0 && (be & 63) == lane) id[be] = kNoIdx;
     if (lane == 0) {
-      a.out_idx[row * a.k + t] = a.col_offset + (int64_t)bi;
-      a.out_val[row * a.k + t] = val_from_key<METRIC>(bk);
+      a.out_idx[row * a.out_stride + a.out_off + t] = a.col_offset + (int64_t)bi;
+      a.out_val[row * a.out_stride + a.out_off + t] = val_from_key<METRIC>(bk);
+      if (a.floor_key_out && t == a.k - 1) { a.floor_key_out[pos] = bk; a.floor_id_out[pos] = bi; }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
@@ -699,8 +703,8 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
       }
       if (be >= 0 && (be & 63) == lane) id[be] = kNoIdx;
       if (lane == 0) {
-        a.out_idx[(int64_t)pos * a.k + t] = a.col_offset + (int64_t)bi;
-        a.out_val[(int64_t)pos * a.k + t] = val_from_key<METRIC>(bk);
+        a.out_idx[(int64_t)pos * a.out_stride + a.out_off + t] = a.col_offset + (int64_t)bi;
+        a.out_val[(int64_t)pos * a.out_stride + a.out_off + t] = val_from_key<METRIC>(bk);
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_wave_barrier();
@@ -820,6 +824,8 @@ int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
     MMF_HIP(hipMemsetAsync(a.defer_cnt, 0, 2048, s));
   }
   a.out_idx = p.out_idx; a.out_val = p.out_val;
+  a.out_stride = p.out_stride > 0 ? p.out_stride : p.k; a.out_off = p.out_off;
+  a.floor_key_out = p.floor_key_out; a.floor_id_out = p.floor_id_out;
   a.fail_rows = p.fail_rows; a.fail_count = p.fail_count; a.cand_total = p.cand_total;
   const bool v4 = p.dtype == MMF_F32 && (p.d % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0) &&
                   ((reinterpret_cast<uintptr_t>(p.Y) & 15) == 0);

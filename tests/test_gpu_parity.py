@@ -84,8 +84,25 @@ def test_simtopk_large_k(mmf, metric, n, d, k, exclude):
     else:
         Y = unit_rows(n + 50, d, 7).numpy()
         check_topk(mmf, X, Y, metric, k, precision="auto")
-    with pytest.raises(RuntimeError, match="supported maximum"):
-        mmf.simtopk(dev(X), metric=metric, k=45)
+
+
+@pytest.mark.parametrize("metric", ["dot", "cosine", "neg_sq_l2", "rbf"])
+@pytest.mark.parametrize("n,d,k,exclude", [(400, 64, 45, True), (1000, 128, 64, True), (3000, 512, 100, True), (700, 96, 44 * 3, False),
+                                           (600, 1024, 87, True)])
+def test_simtopk_k_beyond_one_pass(mmf, metric, n, d, k, exclude):
+    """k + self > 44 (round 3): several passes of the exact scan, each offering only the columns that rank strictly after the
+    previous pass's last entry in the total order (key desc, id asc).  scikit-learn's n_neighbors has no cap (:379).  Against the
+    oracle: indices bit-exact, scores bitwise (rbf to 1e-5); duplicate rows make ties that straddle the pass boundaries."""
+    X = unit_rows(n, d, 500 + n + k).numpy()
+    X[50:90] = X[50]                                # 40 exact copies: equal keys, ids decide — also across a pass boundary
+    if exclude:
+        check_topk(mmf, X, None, metric, k, precision="auto")
+    else:
+        Y = unit_rows(n + 50, d, 9).numpy()
+        Y[10:70] = Y[10]
+        check_topk(mmf, X, Y, metric, k, precision="auto", exclude_self=False)
+    with pytest.raises(RuntimeError, match="does not support"):
+        mmf.simtopk(dev(X), metric=metric, k=k, precision="fast")
 
 
 @pytest.mark.parametrize("metric", ["dot", "cosine", "neg_sq_l2", "rbf"])
