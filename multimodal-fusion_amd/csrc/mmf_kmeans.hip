@@ -19,6 +19,8 @@
 //
 // Bounds: the distance contractions (f64 MFMA, 78.6 TFLOP/s = 3.93e13 multiply-adds/s on MI355X); everything else is
 // HBM-bound and small.  Algorithmic work per Lloyd iteration: n * n_init * k * d multiply-adds.
+#include <type_traits>
+
 #include "mmf_dev.h"
 #include "mmf_host.h"
 
@@ -81,7 +83,15 @@ __global__ void km_colfin_kernel(const double* __restrict__ partial, int64_t nbl
   const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= d) return;
   double s = 0.0;
-  for (int64_t b = 0; b < nblk; ++b) s += partial[b * d + col];
+  int64_t b = 0;
+  for (; b + 8 <= nblk; b += 8) {                     // eight partials in flight, added in order
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[(b + u) * d + col];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; b < nblk; ++b) s += partial[b * d + col];
   s /= (double)n;
   out64[col] = s;
   if (out32) out32[col] = (float)s;
@@ -199,17 +209,19 @@ __device__ __forceinline__ void km_stage_store(double* dst, const float4& v) {
 }
 
 // rowp[2] / ptp[2]: this thread's two staging rows (row t >> 3 and 32 + (t >> 3) of the tile) at column 4 (t & 7).
-// MT = 16-row MFMA tiles per wave: 4 -> tile 64 rows x 64 points, wave w owns points 16 w .. against all rows; 2 -> tile 64 rows x
+// MT = 16-row MFMA tiles per wave.  Plain form: tile (16 MT) rows x 64 points, wave w owns points 16 w .. against all rows (MT < 4:
+// the last, partly filled row tile of the E step — k = 100 is 64 + 48 rows, not 128).  SPLIT form (MT = 2): tile 64 rows x
 // 32 points, wave w owns rows 32 (w & 1) .. and points 16 (w >> 1) .. (twice the workgroups when 64-point tiles would leave the
 // chip with one wave per SIMD and nothing to hide the global loads behind).  Global loads run TWO chunks ahead of the MFMAs.
-template <int MT>
+template <int MT, bool SPLIT>
 __device__ __forceinline__ void km_tile_dots(const float* const rowp[2], const float* const ptp[2], int64_t nchunks, double* As, double* Bs,
                                              f64x4 acc[MT]) {
-  constexpr int NB = MT / 2;                 // staging rows of the point tile per thread
+  static_assert(!SPLIT || MT == 2, "the split form is 2 x 16 rows per wave");
+  constexpr int NB = SPLIT ? 1 : 2;          // staging rows of the point tile per thread (32 or 64 points)
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4;
   const int sr = t >> 3, sk = (t & 7) * 4;
-  const int arow0 = (MT == 4) ? 0 : 32 * (w & 1);
-  const int bpt = (MT == 4) ? 16 * w : 16 * (w >> 1);
+  const int arow0 = SPLIT ? 32 * (w & 1) : 0;
+  const int bpt = SPLIT ? 16 * (w >> 1) : 16 * w;
   float4 ra[2][2], rb[2][NB];
   auto gload = [&](int st, int64_t c) {
 #pragma unroll
@@ -289,8 +301,9 @@ __global__ __launch_bounds__(256, 2) void km_seed_dots_kernel(const float* __res
     ptp[u] = Xc + p * ds + (t & 7) * 4;
   }
   // what the epilogue needs from memory is requested before the contraction: |c_r|^2 of this lane's rows, |x_p|^2 of its point
-  const int arow0 = (MT == 4) ? 0 : 32 * (w & 1);
-  const int bpt = (MT == 4) ? 16 * w : 16 * (w >> 1);
+  constexpr bool SPLIT = MT == 2;
+  const int arow0 = SPLIT ? 32 * (w & 1) : 0;
+  const int bpt = SPLIT ? 16 * (w >> 1) : 16 * w;
   double cr[MT][4];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -315,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void km_seed_dots_kernel(const float* __res
   f64x4 acc[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = f64x4{0.0, 0.0, 0.0, 0.0};
-  km_tile_dots<MT>(rowp, ptp, ds / KM_KC, As, Bs, acc);
+  km_tile_dots<MT, MT == 2>(rowp, ptp, ds / KM_KC, As, Bs, acc);
   // epilogue through LDS: [64 rows][PT + 1] f32
   float* T = reinterpret_cast<float*>(km_lds);
 #pragma unroll
@@ -379,20 +392,29 @@ __global__ __launch_bounds__(256, 2) void km_assign_kernel(const float* __restri
       if (r >= k) r = k - 1;
       rowp[u] = C + r * ds + (t & 7) * 4;
     }
-    f64x4 acc[4];
+    // the row tile's height in 16-row MFMA tiles: only the last tile of a restart's centres is partly filled
+    const int64_t left = k - r0;
+    auto tile = [&](auto mt_tag) {
+      constexpr int MT = decltype(mt_tag)::value;
+      f64x4 acc[MT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] = f64x4{0.0, 0.0, 0.0, 0.0};
-    km_tile_dots<4>(rowp, ptp, ds / KM_KC, As, Bs, acc);
+      for (int m = 0; m < MT; ++m) acc[m] = f64x4{0.0, 0.0, 0.0, 0.0};
+      km_tile_dots<MT, false>(rowp, ptp, ds / KM_KC, As, Bs, acc);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int64_t r = r0 + 16 * m + 4 * v + (lane >> 4);     // ascending in (m, v) for a lane: strict < keeps the first minimum
-        if (r < k) {
-          const double s = ccg[r] - 2.0 * acc[m][v];
-          if (s < best) { best = s; bi = (int)r; }
+        for (int v = 0; v < 4; ++v) {
+          const int64_t r = r0 + 16 * m + 4 * v + (lane >> 4);     // ascending in (m, v) for a lane: strict < keeps the first minimum
+          if (r < k) {
+            const double s = ccg[r] - 2.0 * acc[m][v];
+            if (s < best) { best = s; bi = (int)r; }
+          }
         }
-      }
+    };
+    if (left > 48) tile(std::integral_constant<int, 4>{});
+    else if (left > 32) tile(std::integral_constant<int, 3>{});
+    else if (left > 16) tile(std::integral_constant<int, 2>{});
+    else tile(std::integral_constant<int, 1>{});
   }
 #pragma unroll
   for (int o = 16; o <= 32; o <<= 1) {
@@ -579,11 +601,27 @@ __global__ __launch_bounds__(256) void km_update_kernel(const float* __restrict_
   const int64_t base = (int64_t)g * n;
   double acc = 0.0;
   if (live) {
+    // eight row loads in flight per wave; the member indices of the NEXT trip are read while this trip's rows arrive (index -> row
+    // is two dependent round trips otherwise).  The adds stay in member order.
     int64_t q = b + w;
-    for (; q + 12 < e; q += 16) {
-      const int64_t r0 = order[q] - base, r1 = order[q + 4] - base, r2 = order[q + 8] - base, r3 = order[q + 12] - base;
-      const float x0 = Xc[r0 * ds + col], x1 = Xc[r1 * ds + col], x2 = Xc[r2 * ds + col], x3 = Xc[r3 * ds + col];
-      acc += (double)x0; acc += (double)x1; acc += (double)x2; acc += (double)x3;
+    int64_t r[8];
+    bool more = q + 28 < e;
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] = order[q + 4 * u] - base;
+    }
+    while (more) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = Xc[r[u] * ds + col];
+      q += 32;
+      more = q + 28 < e;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = order[q + 4 * u] - base;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)x[u];
     }
     for (; q < e; q += 4) acc += (double)Xc[(order[q] - base) * ds + col];
   }
