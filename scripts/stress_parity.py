@@ -15,7 +15,7 @@ for case in range(cases):
     n = int(rng.randint(1, 900))
     m = int(rng.randint(45, 4000))
     d = int(rng.choice([1, 2, 3, 7, 16, 31, 64, 100, 129, 255, 256, 300, 512, 513, 777, 1024, 1100, 1536]))
-    k = int(rng.choice([1, 3, 5, 8, 11, 16, 19, 20, 21, 27, 32, 40, 43]))
+    k = int(rng.choice([1, 3, 5, 8, 11, 16, 19, 20, 21, 27, 32, 40, 43, 44, 45, 64, 90, 130]))
     metric = metrics[int(rng.randint(0, 4))]
     dt = dtypes[int(rng.randint(0, 3))]
     excl = bool(rng.randint(0, 2))

@@ -165,3 +165,16 @@ def test_d1024_k16_on_the_split_k_kernel_every_row(mmf):
     X = make(32768, 1024, 11).half()
     whole_result(mmf, X, None, "cosine", 16, True, precisions=("fast",), oracle_rows=32)
     whole_result(mmf, make(16384, 700, 12), None, "neg_sq_l2", 19, True, precisions=("fast",), oracle_rows=16)
+
+
+def test_clustered_bench_workload_every_row(mmf):
+    """`bench.py --data clustered` (N = 262144 rows in 2048 tight clusters: every row's margin band is its whole cluster, 129
+    candidates per row): the grouped matrix-core re-rank of the rows with overflow lists (rerank_group_kernel) against the
+    exact scan over every row, f16 and bf16 operands, and 64 oracle rows."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_rows
+    X = make_rows(0, 262144, 512, torch.device("cuda", 0), data="clustered")
+    whole_result(mmf, X, None, "cosine", 5, True, oracle_rows=64)
+    _, _, st = mmf.simtopk(X, metric="cosine", k=5, precision="fast", return_stats=True)
+    assert st["fallback_rows"] == 0 and st["candidates"] > 100 * 262144, st
