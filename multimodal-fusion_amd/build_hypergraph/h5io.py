@@ -87,3 +87,55 @@ def jsonable(obj):
 
 def dumps_stats(stats) -> str:
     return json.dumps(jsonable(stats))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the CONSUMER's view of the layout: what downstream_survival/ reads back
+# ---------------------------------------------------------------------------------------------------------------------
+HYPERGRAPH_CHANNELS = ("hypergraph=wsi_super_features", "hypergraph=tma_features", "hypergraph=edge_index",
+                       "hypergraph=edge_weights")
+
+
+def _standardize(arr) -> np.ndarray:
+    """2-D float32, as multimodal_dataset.py:454-463 hands every non-index array to the model."""
+    arr = np.asarray(arr)
+    if arr.ndim == 1:
+        arr = arr.reshape(1, arr.shape[0])
+    elif arr.ndim > 2:
+        arr = arr.reshape(arr.shape[0], -1)
+    return arr.astype(np.float32, copy=False)
+
+
+def read_hypergraph_channels(h5_path: str, channels=HYPERGRAPH_CHANNELS) -> dict:
+    """The `hypergraph=<key>` channels of a processed file as the training data set reads them
+    (downstream_survival/datasets/multimodal_dataset.py:342-386): `wsi_super_features` <- hypergraph/wsi_super/features (falls
+    back to wsi/features), `tma_features` <- hypergraph/tma/features (falls back to tma/features), `edge_index` <-
+    hypergraph/edge_index as int64, `edge_weights` <- hypergraph/edge_weights (optional).  Arrays other than edge_index come
+    back as 2-D float32 torch tensors (a 1-D edge_weights vector becomes [1, E], as upstream).  This is the contract the writer
+    (save_hypergraph_to_h5) is tested against; the data set class itself is outside this package's scope."""
+    import torch
+    out = {}
+    with open_file(h5_path, "r") as f:
+        for channel in channels:
+            if not channel.startswith("hypergraph="):
+                raise ValueError(f"not a hypergraph channel: {channel}")
+            key = channel[len("hypergraph="):]
+            if "hypergraph" not in f:
+                raise AssertionError("Hypergraph data not found in h5 file")
+            hg = f["hypergraph"]
+            if key == "wsi_super_features":
+                src = hg["wsi_super"]["features"] if ("wsi_super" in hg and "features" in hg["wsi_super"]) else f["wsi"]["features"]
+                out[channel] = torch.from_numpy(_standardize(src[:]))
+            elif key == "tma_features":
+                src = hg["tma"]["features"] if ("tma" in hg and "features" in hg["tma"]) else f["tma"]["features"]
+                out[channel] = torch.from_numpy(_standardize(src[:]))
+            elif key == "edge_index":
+                if "edge_index" not in hg:
+                    raise AssertionError("Failed to read hypergraph edge_index")
+                out[channel] = torch.from_numpy(np.asarray(hg["edge_index"][:])).long()
+            elif key == "edge_weights":
+                if "edge_weights" in hg:                      # optional upstream
+                    out[channel] = torch.from_numpy(_standardize(hg["edge_weights"][:]))
+            else:
+                raise AssertionError(f"Unknown hypergraph key: {key}")
+    return out

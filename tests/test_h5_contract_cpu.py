@@ -112,3 +112,31 @@ def test_h5py_is_only_needed_when_a_file_is_opened():
     except ImportError:
         with pytest.raises(ImportError, match="h5py"):
             b.load_wsi_data("nowhere.h5")
+
+
+def test_written_hypergraph_reads_back_through_the_consumers_channels(env):
+    """What save_hypergraph_to_h5 writes is what the training data set's `hypergraph=<key>` channels read
+    (downstream_survival/datasets/multimodal_dataset.py:342-386, restated in h5io.read_hypergraph_channels): names, dtypes,
+    shapes, the [2, E] int64 index, the fallbacks to the raw wsi / tma features."""
+    b, store = env
+    rng = np.random.RandomState(1)
+    store.new_case("q.h5", rng.randn(9, 4).astype(np.float32), rng.rand(9, 2).astype(np.float32), rng.randn(3, 4).astype(np.float32))
+    sf, sp, tf = torch.rand(5, 4), torch.rand(5, 2), torch.rand(3, 4)
+    ei = torch.tensor([[0, 0, 1, 2], [1, 2, 2, 7]], dtype=torch.int64)
+    ew = torch.tensor([0.5, 0.25, 1.0, 0.0])
+    b.save_hypergraph_to_h5("q.h5", sf, sp, tf, ei, ew, np.zeros(5, np.int32), {"k": 1})
+    ch = b.h5io.read_hypergraph_channels("q.h5")
+    assert set(ch) == set(b.h5io.HYPERGRAPH_CHANNELS)
+    assert torch.equal(ch["hypergraph=wsi_super_features"], sf) and ch["hypergraph=wsi_super_features"].dtype == torch.float32
+    assert torch.equal(ch["hypergraph=tma_features"], tf)
+    assert torch.equal(ch["hypergraph=edge_index"], ei) and ch["hypergraph=edge_index"].dtype == torch.int64
+    assert torch.equal(ch["hypergraph=edge_weights"], ew[None, :])            # 1-D -> [1, E], as upstream's _standardize_array
+    # a file whose hypergraph group lacks the feature copies: the reader falls back to the raw features (:353-369)
+    with store("q.h5", "a") as f:
+        del f["hypergraph"]["wsi_super"]
+        del f["hypergraph"]["tma"]
+    ch = b.h5io.read_hypergraph_channels("q.h5", ("hypergraph=wsi_super_features", "hypergraph=tma_features"))
+    assert tuple(ch["hypergraph=wsi_super_features"].shape) == (9, 4) and tuple(ch["hypergraph=tma_features"].shape) == (3, 4)
+    store.new_case("r.h5", rng.randn(2, 4).astype(np.float32))
+    with pytest.raises(AssertionError, match="Hypergraph data not found"):
+        b.h5io.read_hypergraph_channels("r.h5")
