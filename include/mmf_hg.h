@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 2
+#define MMF_ABI_VERSION 3
 
 /* return codes */
 #define MMF_OK             0
@@ -75,6 +75,15 @@ extern "C" {
                              lists go to a per-row overflow list, rows that exhaust it are rescanned exactly */
 #define MMF_PREC_FAST_BF16 3 /* same with bf16 operands: 8x larger rounding residual, wider margin    */
 
+/* order in which the 16-bit scan takes its query rows (mmf_simtopk_opts.query_order).  A scan wave serves 32 consecutive
+ * queries and leaves its matrix-core loop whenever any of them has a column inside its margin, so on near-duplicate data
+ * (patch embeddings) it pays to put near-duplicate rows next to each other.  The order is an internal matter of the scan:
+ * outputs stay in the caller's row order and their bits do not depend on it. */
+#define MMF_QUERY_ORDER_AUTO 0 /* n, m >= 32768: measure (nearest of 256 pivot rows per query, one small matrix-core pass and one
+                                  host synchronisation) and reorder when the rows have near-duplicates; smaller: row order */
+#define MMF_QUERY_ORDER_OFF  1 /* the caller's row order                                                                     */
+#define MMF_QUERY_ORDER_ON   2 /* always reorder (tests)                                                                      */
+
 int         mmf_version(void);
 const char* mmf_last_error(void);
 
@@ -103,7 +112,7 @@ typedef struct mmf_simtopk_opts {
   int      precision;      /* MMF_PREC_*                                                        */
   int      profile;        /* 1: bracket the scan kernel with HIP events on hip_stream           */
   int      col_splits;     /* 0 = auto; >0 forces the number of column ranges per row block      */
-  int      reserved0;
+  int      query_order;    /* MMF_QUERY_ORDER_*: order in which the 16-bit scan takes the query rows (results do not depend on it) */
   void*    select_wait_event; /* optional hipEvent_t: the stream waits for it after the 16-bit scan and
                                  before anything reads the f32 rows of X / Y (overlapped all-gather)    */
 } mmf_simtopk_opts;
@@ -122,6 +131,9 @@ typedef struct mmf_simtopk_stats {
                               ready_events (exposed exchange time), 0 otherwise                   */
   int64_t  overflow_rows;  /* fallback rows whose candidate list overflowed (near-ties beyond capacity) */
   int64_t  short_rows;     /* fallback rows whose lists held fewer than k admissible candidates   */
+  int64_t  near_rows;      /* query rows within cosine 0.98 of the nearest of 256 pivot rows (-1: not measured)  */
+  float    order_ms;       /* profile = 1: pivot keys + sort + gather of the query order (0 when not tried)      */
+  int      query_order;    /* 1: the scan took the queries with near-duplicate rows next to each other           */
 } mmf_simtopk_stats;
 
 int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d,

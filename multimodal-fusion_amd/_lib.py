@@ -13,12 +13,13 @@ DOT, COSINE, NEG_SQ_L2, RBF, RBF_DIRECT = 0, 1, 2, 3, 4
 METRICS = {"dot": DOT, "cosine": COSINE, "neg_sq_l2": NEG_SQ_L2, "rbf": RBF, "rbf_direct": RBF_DIRECT}
 F32, BF16, F16 = 0, 1, 2
 PRECISIONS = {"auto": 0, "exact": 1, "fast": 2, "fast_bf16": 3}
-ABI_VERSION = 2          # MMF_ABI_VERSION of the include/mmf_hg.h this binding was written against
+QUERY_ORDERS = {"auto": 0, "off": 1, "on": 2}
+ABI_VERSION = 3          # MMF_ABI_VERSION of the include/mmf_hg.h this binding was written against
 
 
 class SimtopkOpts(ctypes.Structure):
     _fields_ = [("precision", ctypes.c_int), ("profile", ctypes.c_int), ("col_splits", ctypes.c_int),
-                ("reserved0", ctypes.c_int), ("select_wait_event", ctypes.c_void_p)]
+                ("query_order", ctypes.c_int), ("select_wait_event", ctypes.c_void_p)]
 
 
 class PreparedSide(ctypes.Structure):
@@ -36,7 +37,8 @@ class SimtopkStats(ctypes.Structure):
     _fields_ = [("scan_ms", ctypes.c_float), ("prep_ms", ctypes.c_float), ("rerank_ms", ctypes.c_float),
                 ("fallback_ms", ctypes.c_float), ("candidates", ctypes.c_int64), ("fallback_rows", ctypes.c_int64),
                 ("precision_used", ctypes.c_int), ("col_splits", ctypes.c_int), ("scan_grid", ctypes.c_int),
-                ("scan_wait_ms", ctypes.c_float), ("overflow_rows", ctypes.c_int64), ("short_rows", ctypes.c_int64)]
+                ("scan_wait_ms", ctypes.c_float), ("overflow_rows", ctypes.c_int64), ("short_rows", ctypes.c_int64),
+                ("near_rows", ctypes.c_int64), ("order_ms", ctypes.c_float), ("query_order", ctypes.c_int)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_ if not f.startswith("reserved")}

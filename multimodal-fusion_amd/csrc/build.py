@@ -18,7 +18,7 @@ PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 OUT = os.path.join(PKG, "libmmf_hg.so")
 OBJ = os.path.join(HERE, "_obj")
-SOURCES = ["mmf_api.hip", "mmf_prep.hip", "mmf_scan_f32.hip", "mmf_scan_bf16.hip", "mmf_select.hip", "mmf_edges.hip", "mmf_segments.hip", "mmf_direct.hip", "mmf_kmeans.hip"]
+SOURCES = ["mmf_api.hip", "mmf_prep.hip", "mmf_scan_f32.hip", "mmf_scan_bf16.hip", "mmf_select.hip", "mmf_edges.hip", "mmf_segments.hip", "mmf_direct.hip", "mmf_kmeans.hip", "mmf_order.hip"]
 HEADERS = ["mmf_dev.h", "mmf_host.h", os.path.join(ROOT, "include", "mmf_hg.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-std=c++17", "-fno-gpu-rdc",

@@ -162,6 +162,8 @@ struct FastOperands {
   // paneled scan (mmf_simtopk_panels): the candidate operands come as n_panels separate blocks, each scanned by
   // its own launch once its event has fired; ZC / c_cb / m_pad_tiles above are then unused
   const mmf_panel* panels = nullptr; int n_panels = 0;
+  // ZQ / q_zn / q_rn / q_un hold the queries in scan order: position p is row perm[p] (mmf_order.hip); null: row order
+  const int32_t* perm = nullptr;
 };
 
 struct FastTail {
@@ -171,6 +173,17 @@ struct FastTail {
   uint32_t *fail_count = nullptr, *cand_total = nullptr, *fb_fail_count = nullptr;
   char* scan_scratch = nullptr;
   char* order_scratch = nullptr;
+  // query order of the scan (mmf_order.hip): near-duplicate rows next to each other.  Tried when forced, or (auto) at sizes where
+  // the scan dominates; applied when the rows have near-duplicates among themselves (decided from the data, one host sync).
+  int order_mode = MMF_QUERY_ORDER_OFF; bool order_try = false;
+  char* qo_scratch = nullptr; uint16_t* qo_Z = nullptr; float *qo_zn = nullptr, *qo_rn = nullptr, *qo_un = nullptr;
+  int64_t n_pad_q() const { return (n + 255) / 256 * 256; }
+  int set_query_order(int mode) {   // before bytes() / carve()
+    if (mode < MMF_QUERY_ORDER_AUTO || mode > MMF_QUERY_ORDER_ON) { set_error("simtopk: bad query_order %d", mode); return MMF_E_INVALID; }
+    order_mode = mode;
+    order_try = mode == MMF_QUERY_ORDER_ON || (mode == MMF_QUERY_ORDER_AUTO && n >= 32768 && m >= 32768);
+    return MMF_OK;
+  }
 
   int dp, panels;
   int panel_splits[16]; int max_splits = 1;
@@ -234,7 +247,8 @@ struct FastTail {
     return ws_bytes((size_t)n * lists, 4) + 2 * ws_bytes((size_t)n * lists * bcap, 4) + 3 * ws_bytes(n, 4) + ws_bytes(4, 4) +
            ws_bytes(256, 4) + ws_bytes((size_t)FB * fb_lists, 4) + ws_bytes((size_t)FB * fb_lists * cap, 4) +
            2 * ws_bytes(FB, 4) + ws_bytes(4, 4) + ws_bytes(scan_b16_scratch_bytes(n, max_splits, dp, bcap), 1) + ws_bytes(2 * n_seed, 4) +
-           ws_bytes((size_t)rows_exact_cap * m, 4) + ws_bytes(n, 4) + ws_bytes((size_t)n * kSpillCap, 4) + ws_bytes(select_order_bytes(n), 1);
+           ws_bytes((size_t)rows_exact_cap * m, 4) + ws_bytes(n, 4) + ws_bytes((size_t)n * kSpillCap, 4) + ws_bytes(select_order_bytes(n), 1) +
+           (order_try ? ws_bytes(query_order_bytes(n), 1) + ws_bytes((size_t)n_pad_q() * dp, 2) + 3 * ws_bytes(n_pad_q(), 4) : 0);
   }
   void carve(Workspace& ws) {
     L.cnt = ws.take<uint32_t>((size_t)n * lists);
@@ -261,10 +275,27 @@ struct FastTail {
     L.spill_cap = kSpillCap;
     L.spill_stacks = (lists == 2 && kSpillCap < 65536 && !getenv("MMF_SPILL_COUNTER")) ? 1 : 0;
     order_scratch = ws.take<char>(select_order_bytes(n));
+    if (order_try) {
+      qo_scratch = ws.take<char>(query_order_bytes(n));
+      qo_Z = ws.take<uint16_t>((size_t)n_pad_q() * dp);
+      qo_zn = ws.take<float>(n_pad_q()); qo_rn = ws.take<float>(n_pad_q()); qo_un = ws.take<float>(n_pad_q());
+    }
   }
   int run(const void* X, int64_t n_, const void* Y, int64_t m_, int64_t d, int in_dtype, int metric, float lambda, int k,
-          int exclude_self, int64_t row_offset, int64_t col_offset, const FastOperands& fo, int64_t* out_idx,
+          int exclude_self, int64_t row_offset, int64_t col_offset, const FastOperands& fo_in, int64_t* out_idx,
           float* out_val, bool profile, void* select_wait_event, mmf_simtopk_stats* stats, int precision, hipStream_t s) {
+    FastOperands fo = fo_in;
+    EventTimer t_order;
+    int64_t near_rows = -1;
+    if (order_try) {
+      MMF_TRY(t_order.start(profile, s));
+      MMF_TRY(launch_query_order_keys(fo.ZQ, fo.q_zn, n, fo.dp, fo.f16, qo_scratch, &near_rows, s));
+      if (order_mode == MMF_QUERY_ORDER_ON || near_rows >= 4 * (int64_t)query_order_pivots()) {
+        MMF_TRY(launch_query_order_apply(fo.ZQ, fo.q_zn, fo.q_rn, fo.q_un, n, n_pad_q(), fo.dp, qo_scratch, qo_Z, qo_zn, qo_rn, qo_un, &fo.perm, s));
+        fo.ZQ = qo_Z; fo.q_zn = qo_zn; fo.q_rn = qo_rn; fo.q_un = qo_un;
+      }
+      MMF_TRY(t_order.stop(s));
+    }
     MMF_HIP(hipMemsetAsync(L.overflow, 0, (size_t)n * 4, s));
     MMF_HIP(hipMemsetAsync(fail_count, 0, 16, s));
     MMF_HIP(hipMemsetAsync(cand_total, 0, 1024, s));
@@ -309,7 +340,7 @@ struct FastTail {
     SelectProblem q{};
     q.X = X; q.n = n; q.Y = Y; q.m = m; q.d = d; q.dtype = in_dtype; q.metric = metric; q.lambda = lambda;
     q.k = k; q.exclude_self = exclude_self; q.row_offset = row_offset; q.col_offset = col_offset;
-    q.rx = fo.rx; q.cy = fo.cy; q.row_ids = nullptr; q.n_rows = n; q.out_idx = out_idx; q.out_val = out_val;
+    q.rx = fo.rx; q.cy = fo.cy; q.row_ids = nullptr; q.perm = fo.perm; q.n_rows = n; q.out_idx = out_idx; q.out_val = out_val;
     q.fail_rows = fail_rows; q.fail_count = fail_count; q.cand_total = stats ? cand_total : nullptr;
     q.two_pass = true;
     q.order_scratch = getenv("MMF_SELECT_UNORDERED") ? nullptr : order_scratch;
@@ -341,6 +372,7 @@ struct FastTail {
     if (h_fail > 0 && (int64_t)h_fail <= kRowsExactMax) {
       for (int64_t off = 0; off < (int64_t)h_fail; off += rows_exact_cap) {
         SelectProblem fq = q;
+        fq.perm = nullptr;
         fq.row_ids = fail_rows + off;
         fq.n_rows = ((int64_t)h_fail - off < rows_exact_cap) ? ((int64_t)h_fail - off) : rows_exact_cap;
         MMF_TRY(launch_rows_exact(fq, row_keys, s));
@@ -367,6 +399,7 @@ struct FastTail {
       sp.kk = kk; sp.rx = fo.rx; sp.cy = fo.cy; sp.row_ids = fail_rows + off; sp.n_rows = nb; sp.col_splits = fb_splits;
       MMF_TRY(launch_scan_f32(sp, FL, s, nullptr));
       SelectProblem fq = q;
+      fq.perm = nullptr;
       fq.row_ids = fail_rows + off; fq.n_rows = nb; fq.fail_rows = fb_fail_rows; fq.fail_count = fb_fail_count;
       fq.cand_total = nullptr;
       MMF_TRY(launch_select(fq, FL, s));
@@ -399,6 +432,9 @@ struct FastTail {
       int64_t tot = 0;
       for (uint32_t v : h_tot) tot += v;
       stats->candidates = tot;
+      stats->near_rows = near_rows;
+      stats->order_ms = t_order.ms();
+      stats->query_order = fo.perm ? 1 : 0;
     }
     (void)n_; (void)m_;
     return MMF_OK;
@@ -497,6 +533,7 @@ int mmf_simtopk_ex(const void* X, int64_t n, const void* Y, int64_t m, int64_t d
     const bool shared = same || slice0 >= 0;
     const int64_t n_pad = (n + 255) / 256 * 256, m_pad = (m + 255) / 256 * 256 + (slice0 >= 0 ? 256 : 0);
     FastTail ft(n, m, kk, cap, forced_splits, dp);
+    MMF_TRY(ft.set_query_order(opts ? opts->query_order : MMF_QUERY_ORDER_AUTO));
     size_t need = ws_bytes(n, 4) + ws_bytes(m, 4) + ws_bytes((size_t)n_pad * dp, 2) + ws_bytes((size_t)m_pad * dp, 2) +
                   4 * ws_bytes(n_pad, 4) + 4 * ws_bytes(m_pad, 4) + 3 * ws_bytes(4, 4) + ft.bytes();
     Workspace ws;
@@ -699,6 +736,7 @@ int mmf_simtopk_prepared(const void* X, int64_t n, const void* Y, int64_t m, int
   DeviceGuard guard(device_id);
   if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
   FastTail ft(n, m, kk, cap, opts ? opts->col_splits : 0, scan_bf16_dp(d));
+  MMF_TRY(ft.set_query_order(opts ? opts->query_order : MMF_QUERY_ORDER_AUTO));
   Workspace ws;
   MMF_TRY(get_workspace(device_id, s, ft.bytes(), &ws));
   ft.carve(ws);
@@ -748,6 +786,7 @@ int mmf_simtopk_panels(const void* X, int64_t n, const void* Y, int64_t m, int64
   DeviceGuard guard(device_id);
   if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return MMF_E_HIP; }
   FastTail ft(n, m, kk, cap, opts ? opts->col_splits : 0, scan_bf16_dp(d), n_panels, m_min, m_max);
+  MMF_TRY(ft.set_query_order(opts ? opts->query_order : MMF_QUERY_ORDER_AUTO));
   if ((int64_t)ft.lists * ft.bcap + FastTail::kSpillCap > 1024) {
     set_error("simtopk_panels: %d panels x %d-entry lists exceed the 1024 candidates a row can hand to the re-rank (k = %d): use fewer panels", n_panels, ft.bcap, k);
     return MMF_E_UNSUPPORTED;

@@ -155,8 +155,17 @@ struct SelectProblem {
   float* floor_key_out = nullptr;        // optional: key and LOCAL column id of the last entry emitted per row (the next pass's floor)
   uint32_t* floor_id_out = nullptr;
   void* order_scratch = nullptr;   // select_order_bytes(n_rows): that second launch walks its rows ordered by their smallest candidate id
+  const int32_t* perm = nullptr;   // optional (row_ids must be null): list position -> row of X, a permutation of 0 .. n_rows - 1 — the scan
+                                   // took its queries in that order (mmf_order.hip); X, rx, the outputs and fail_rows stay in row order
 };
 size_t select_order_bytes(int64_t n);
+// mmf_order.hip: the order in which the 16-bit scan takes its query rows (near-duplicate rows next to each other)
+size_t query_order_bytes(int64_t n);
+int query_order_pivots();
+int launch_query_order_keys(const uint16_t* ZQ, const float* q_zn, int64_t n, int dp, bool f16, void* scratch, int64_t* near, hipStream_t s);
+int launch_query_order_apply(const uint16_t* ZQ, const float* q_zn, const float* q_rn, const float* q_un, int64_t n, int64_t n_pad,
+                             int dp, void* scratch, uint16_t* Zo, float* zno, float* rno, float* uno, const int32_t** perm,
+                             hipStream_t s);
 int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s);
 // exact top-k of a few rows (p.row_ids) against every column, no candidate lists; keys: p.n_rows * p.m floats
 int launch_rows_exact(const SelectProblem& p, float* keys, hipStream_t s);

@@ -22,7 +22,8 @@ struct SelectArgs {
   const void* X; const void* Y; int64_t n, m, d; int dtype;
   float neg_lambda; int k; int exclude_self; int64_t row_offset, col_offset;
   const float* rx; const float* cy;
-  const int32_t* row_ids; int64_t n_rows;
+  const int32_t* row_ids; int64_t n_rows;            // list position -> row of X (a subset of the rows, or a permutation: is_perm)
+  int is_perm;
   const uint32_t* cand_cnt; const uint32_t* cand_ids; const uint32_t* overflow; int lists; int cap;
   const float* cand_keys; const float* margin;      // optional: approximate keys of the entries + the row's error margin
   int slot_ulp;                                     // ... which carry this many ulps of id-slot bits
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_kernel(SelectArgs a) {
   if (failed) {
     if (lane == 0) {
       const uint32_t slot = atomicAdd(a.fail_count, 1u);
-      a.fail_rows[slot] = (int32_t)pos;
+      a.fail_rows[slot] = (int32_t)row;
       atomicAdd(a.fail_count + (was_overflow ? 1 : 2), 1u);   // reason counters (stats only)
     }
     return;
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
   if (failed) {
     if (lane == 0) {
       const uint32_t slot = atomicAdd(a.fail_count, 1u);
-      a.fail_rows[slot] = (int32_t)pos;
+      a.fail_rows[slot] = (int32_t)row;
       atomicAdd(a.fail_count + (was_overflow ? 1 : 2), 1u);
     }
     continue;
@@ -591,7 +592,8 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
     const int nchunk = (int)((d + GR_KC - 1) / GR_KC);
     const bool qstage = tid < 128;                                    // query tile: 32 rows x 16 k = 128 16-byte pieces
     const int sq_row = (tid >> 2) & 31, sq_k = (tid & 3) * 4;
-    const int64_t qrow = L.qpos[sq_row] >= 0 ? (int64_t)L.qpos[sq_row] : (int64_t)L.qpos[0];
+    const int64_t qpos_s = L.qpos[sq_row] >= 0 ? (int64_t)L.qpos[sq_row] : (int64_t)L.qpos[0];
+    const int64_t qrow = a.row_ids ? (int64_t)a.row_ids[qpos_s] : qpos_s;
     const int c0 = pass * 32 * GR_W + 32 * w;
     const bool active = c0 < np;                                      // waves beyond the panel only keep the barriers
     int64_t prow[2];
@@ -662,8 +664,9 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
     if (pos < 0 || total < 0) continue;
     uint32_t* id = L.cid[q];
     float* key = L.ckey[q];
-    const int64_t grow = a.row_offset + pos;
-    const float ri = a.rx[pos];
+    const int64_t row = a.row_ids ? (int64_t)a.row_ids[pos] : (int64_t)pos;
+    const int64_t grow = a.row_offset + row;
+    const float ri = a.rx[row];
     int valid = 0;
     for (int e = lane; e < total; e += 64) {
       const uint32_t j = id[e];
@@ -703,8 +706,8 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
       }
       if (be >= 0 && (be & 63) == lane) id[be] = kNoIdx;
       if (lane == 0) {
-        a.out_idx[(int64_t)pos * a.out_stride + a.out_off + t] = a.col_offset + (int64_t)bi;
-        a.out_val[(int64_t)pos * a.out_stride + a.out_off + t] = val_from_key<METRIC>(bk);
+        a.out_idx[row * a.out_stride + a.out_off + t] = a.col_offset + (int64_t)bi;
+        a.out_val[row * a.out_stride + a.out_off + t] = val_from_key<METRIC>(bk);
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_wave_barrier();
@@ -717,7 +720,7 @@ template <int METRIC>
 static int launch_select_m(const SelectArgs& a, bool vec4, bool staged16, void* order_temp, size_t order_temp_bytes, hipStream_t s) {
   const int64_t grid = (a.n_rows + SEL_WAVES - 1) / SEL_WAVES;
   if ((vec4 || staged16) && a.d >= 64) {
-    const bool two = a.spill_cnt != nullptr && a.two_pass && a.row_ids == nullptr;
+    const bool two = a.spill_cnt != nullptr && a.two_pass && (a.row_ids == nullptr || a.is_perm);
     for (int pass = 0; pass < (two ? 2 : 1); ++pass) {
       SelectArgs b = a;
       b.pass = pass;
@@ -806,14 +809,18 @@ int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
   a.X = p.X; a.Y = p.Y; a.n = p.n; a.m = p.m; a.d = p.d; a.dtype = p.dtype;
   a.neg_lambda = -p.lambda; a.k = p.k; a.exclude_self = p.exclude_self;
   a.row_offset = p.row_offset; a.col_offset = p.col_offset; a.rx = p.rx; a.cy = p.cy;
-  a.row_ids = p.row_ids; a.n_rows = p.n_rows;
+  a.row_ids = p.row_ids; a.n_rows = p.n_rows; a.is_perm = 0;
+  if (p.perm) {
+    if (p.row_ids) { set_error("select: row_ids and perm are exclusive"); return MMF_E_INTERNAL; }
+    a.row_ids = p.perm; a.is_perm = 1;
+  }
   a.cand_cnt = L.cnt; a.cand_ids = L.ids; a.overflow = L.overflow; a.lists = L.lists; a.cap = L.cap;
   a.cand_keys = L.keys; a.margin = L.margin; a.slot_ulp = L.slot_ulp;
   a.spill_cnt = L.spill_cnt; a.spill_ids = L.spill_ids; a.spill_cap = L.spill_cap; a.spill_stacks = L.spill_stacks;
   a.pass = 0; a.two_pass = p.two_pass ? 1 : 0;
   void* order_temp = nullptr;
   size_t order_temp_bytes = 0;
-  if (p.two_pass && p.order_scratch && p.row_ids == nullptr && L.spill_cnt) {
+  if (p.two_pass && p.order_scratch && p.row_ids == nullptr && L.spill_cnt) {   // (p.perm is fine: the order is one of list positions)
     uint32_t* o = static_cast<uint32_t*>(p.order_scratch);
     const size_t nn = ((size_t)p.n_rows + 63) & ~size_t(63);
     a.key_in = o; a.row_in = o + nn; a.key_sorted = o + 2 * nn; a.row_sorted = o + 3 * nn;

@@ -47,8 +47,10 @@ def _metric(m) -> int:
 
 def simtopk(X: torch.Tensor, Y: Optional[torch.Tensor] = None, *, metric="cosine", lam: float = 1.0, k: int = 5,
             exclude_self: Optional[bool] = None, row_offset: int = 0, col_offset: int = 0, precision: str = "auto",
-            profile: bool = False, col_splits: int = 0, return_stats: bool = False):
-    """Fused similarity + per-row top-k (mmf_simtopk_ex).  Returns (idx int64 [n,k], val f32 [n,k])."""
+            profile: bool = False, col_splits: int = 0, return_stats: bool = False, query_order: str = "auto"):
+    """Fused similarity + per-row top-k (mmf_simtopk_ex).  Returns (idx int64 [n,k], val f32 [n,k]).
+    query_order ("auto" / "off" / "on"): whether the 16-bit scan takes near-duplicate rows next to each other
+    (include/mmf_hg.h MMF_QUERY_ORDER_*; the result does not depend on it)."""
     X = _feat(X, "simtopk X")
     _need_gpu(X, "simtopk")
     if Y is not None:
@@ -61,7 +63,7 @@ def simtopk(X: torch.Tensor, Y: Optional[torch.Tensor] = None, *, metric="cosine
     m = n if Y is None else Y.shape[0]
     idx = torch.empty((n, k), dtype=torch.int64, device=X.device)
     val = torch.empty((n, k), dtype=torch.float32, device=X.device)
-    opts = _lib.SimtopkOpts(_lib.PRECISIONS[precision], int(profile), int(col_splits), 0, None)
+    opts = _lib.SimtopkOpts(_lib.PRECISIONS[precision], int(profile), int(col_splits), _lib.QUERY_ORDERS[query_order], None)
     stats = _lib.SimtopkStats()
     rc = _lib.lib().mmf_simtopk_ex(_p(X), n, _p(Y), m, d, _DT[X.dtype], _metric(metric), float(lam), int(k),
                                    int(bool(exclude_self)), int(row_offset), int(col_offset), _p(idx), _p(val),

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
             "mmf_last_error", "mmf_release_workspaces"} <= set(names)
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/mmf_hg.h but not exported by libmmf_hg.so"
-    assert L.mmf_version() == 2
+    assert L.mmf_version() == 3
 
 
 def test_abi_has_no_cpu_path():
