@@ -217,7 +217,8 @@ def main() -> None:
                 roof["traffic_source"] = "offline rocprofv3 --pmc passes of this command, " + str(ent.get("round", "profiles/"))
         except (OSError, ValueError):
             pass
-        roof.update({"prep_ms": stats["prep_ms"], "rerank_ms": stats["rerank_ms"], "fallback_ms": stats["fallback_ms"]})
+        roof.update({"prep_ms": stats["prep_ms"], "order_ms": stats.get("order_ms", 0.0), "rerank_ms": stats["rerank_ms"],
+                     "fallback_ms": stats["fallback_ms"]})
         par = {"single": "single GPU",
                "simple": f"row-shard x{world}; one all-gather of the f32 shard",
                "pipelined": f"row-shard x{world}; own rows scanned first, 16-bit operands of the other ranks all-gathered under that scan, f32 shard under all of it"}[driver]
@@ -232,7 +233,9 @@ def main() -> None:
                        "scan_kernel": SCAN_NAME[prec], "col_splits": stats["col_splits"],
                        "scan_grid": stats["scan_grid"], "fallback_rows": stats["fallback_rows"],
                        "overflow_rows": stats["overflow_rows"],
-                       "candidates_per_row": stats["candidates"] / max(1, hi - lo)},
+                       "candidates_per_row": stats["candidates"] / max(1, hi - lo),
+                       # the scan's query order (csrc/mmf_order.hip): decided per call from a probe of the rows
+                       "query_order": bool(stats.get("query_order", 0)), "near_duplicate_rows_estimate": stats.get("near_rows", -1)},
             "roofline": roof,
         }
         if check is not None:

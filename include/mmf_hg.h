@@ -79,13 +79,16 @@ extern "C" {
  * queries and leaves its matrix-core loop whenever any of them has a column inside its margin, so on near-duplicate data
  * (patch embeddings) it pays to put near-duplicate rows next to each other.  The order is an internal matter of the scan:
  * outputs stay in the caller's row order and their bits do not depend on it. */
-#define MMF_QUERY_ORDER_AUTO 0 /* n, m >= 32768: measure (nearest of 256 pivot rows per query, one small matrix-core pass and one
-                                  host synchronisation) and reorder when the rows have near-duplicates; smaller: row order */
+#define MMF_QUERY_ORDER_AUTO 0 /* n, m >= 32768: probe (a sample of the rows against 128 pivot rows, one small matrix-core launch and one
+                                  host synchronisation) and reorder when the rows have near-duplicates; smaller: row order   */
 #define MMF_QUERY_ORDER_OFF  1 /* the caller's row order                                                                     */
 #define MMF_QUERY_ORDER_ON   2 /* always reorder (tests)                                                                      */
 
 int         mmf_version(void);
 const char* mmf_last_error(void);
+/* diagnostics: the scan position -> row permutation of the most recent call that reordered its n queries (host buffer, n entries);
+ * valid until the next call on that device / stream or mmf_release_workspaces.  MMF_E_INVALID when there is none. */
+int         mmf_debug_query_order(int32_t* perm_host, int64_t n);
 
 /*
  * Fused similarity + per-row top-k; the N x M matrix never reaches HBM.
@@ -131,7 +134,7 @@ typedef struct mmf_simtopk_stats {
                               ready_events (exposed exchange time), 0 otherwise                   */
   int64_t  overflow_rows;  /* fallback rows whose candidate list overflowed (near-ties beyond capacity) */
   int64_t  short_rows;     /* fallback rows whose lists held fewer than k admissible candidates   */
-  int64_t  near_rows;      /* query rows within cosine 0.98 of the nearest of 256 pivot rows (-1: not measured)  */
+  int64_t  near_rows;      /* estimated query rows within cosine 0.98 of one of 128 pivot rows other than themselves (-1: not probed) */
   float    order_ms;       /* profile = 1: pivot keys + sort + gather of the query order (0 when not tried)      */
   int      query_order;    /* 1: the scan took the queries with near-duplicate rows next to each other           */
 } mmf_simtopk_stats;

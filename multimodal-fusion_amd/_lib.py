@@ -50,7 +50,7 @@ EXPORTS = ["mmf_version", "mmf_last_error", "mmf_simtopk", "mmf_simtopk_ex", "mm
            "mmf_simtopk_prepared", "mmf_simtopk_panels", "mmf_padded_dim", "mmf_fast_scan_supported", "mmf_topk_merge", "mmf_edge_cosine",
            "mmf_sim_dense", "mmf_sim_dense_stats", "mmf_sim_dense_combined", "mmf_offdiag_lower_median", "mmf_threshold_edges", "mmf_threshold_edges_count", "mmf_threshold_edges_fill", "mmf_lower_median", "mmf_array_stats",
            "mmf_segment_sort", "mmf_segment_mean", "mmf_segment_offdiag_mean", "mmf_clique_pairs", "mmf_knn_pairs", "mmf_kmeans_fit", "mmf_combined_offdiag_median", "mmf_combined_threshold_edges",
-           "mmf_release_workspaces"]
+           "mmf_release_workspaces", "mmf_debug_query_order"]
 
 
 def lib() -> ctypes.CDLL:

@@ -289,9 +289,9 @@ struct FastTail {
     int64_t near_rows = -1;
     if (order_try) {
       MMF_TRY(t_order.start(profile, s));
-      MMF_TRY(launch_query_order_keys(fo.ZQ, fo.q_zn, n, fo.dp, fo.f16, qo_scratch, &near_rows, s));
-      if (order_mode == MMF_QUERY_ORDER_ON || near_rows >= 4 * (int64_t)query_order_pivots()) {
-        MMF_TRY(launch_query_order_apply(fo.ZQ, fo.q_zn, fo.q_rn, fo.q_un, n, n_pad_q(), fo.dp, qo_scratch, qo_Z, qo_zn, qo_rn, qo_un, &fo.perm, s));
+      MMF_TRY(launch_query_order_probe(fo.ZQ, fo.q_zn, n, fo.dp, fo.f16, qo_scratch, &near_rows, s));
+      if (order_mode == MMF_QUERY_ORDER_ON || near_rows >= 8 * (int64_t)query_order_pivots()) {
+        MMF_TRY(launch_query_order_apply(fo.ZQ, fo.q_zn, fo.q_rn, fo.q_un, n, n_pad_q(), fo.dp, fo.f16, qo_scratch, qo_Z, qo_zn, qo_rn, qo_un, &fo.perm, s));
         fo.ZQ = qo_Z; fo.q_zn = qo_zn; fo.q_rn = qo_rn; fo.q_un = qo_un;
       }
       MMF_TRY(t_order.stop(s));
@@ -448,6 +448,7 @@ using namespace mmf;
 extern "C" {
 
 int mmf_version(void) { return MMF_ABI_VERSION; }
+int mmf_debug_query_order(int32_t* perm_host, int64_t n) { return query_order_last(perm_host, n); }
 const char* mmf_last_error(void) { return g_err; }
 
 int mmf_release_workspaces(void) {

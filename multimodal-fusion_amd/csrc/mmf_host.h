@@ -162,9 +162,10 @@ size_t select_order_bytes(int64_t n);
 // mmf_order.hip: the order in which the 16-bit scan takes its query rows (near-duplicate rows next to each other)
 size_t query_order_bytes(int64_t n);
 int query_order_pivots();
-int launch_query_order_keys(const uint16_t* ZQ, const float* q_zn, int64_t n, int dp, bool f16, void* scratch, int64_t* near, hipStream_t s);
+int query_order_last(int32_t* out_host, int64_t n);
+int launch_query_order_probe(const uint16_t* ZQ, const float* q_zn, int64_t n, int dp, bool f16, void* scratch, int64_t* near, hipStream_t s);
 int launch_query_order_apply(const uint16_t* ZQ, const float* q_zn, const float* q_rn, const float* q_un, int64_t n, int64_t n_pad,
-                             int dp, void* scratch, uint16_t* Zo, float* zno, float* rno, float* uno, const int32_t** perm,
+                             int dp, bool f16, void* scratch, uint16_t* Zo, float* zno, float* rno, float* uno, const int32_t** perm,
                              hipStream_t s);
 int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s);
 // exact top-k of a few rows (p.row_ids) against every column, no candidate lists; keys: p.n_rows * p.m floats

@@ -7,15 +7,17 @@
 // workload); with near-duplicate rows NEXT to each other the hits of a wave coincide and the same work takes a single visit.
 // Which wave scans for a row changes nothing in the row's result, so the scan may take its queries in any order:
 //
-//   order_keys   every query's nearest of 256 pivot rows (every (n / 256)-th query row), by the cosine of the 16-bit
-//                operands on the matrix cores: key = pivot << 24 | cosine in 24 bits.  Near-duplicate rows agree on the
-//                pivot and, to ~1e-3, on the cosine — whether or not the pivot is one of them.
+//   order_keys   every query's nearest and second-nearest of 128 pivot rows (every (n / 128)-th query row), by the cosine of the
+//                16-bit operands on the matrix cores: key = pivot << 25 | second pivot << 18 | cosine in 18 bits.
+//                Near-duplicate rows agree on both pivots and, to ~1e-3, on the cosine — whether or not a pivot is one of
+//                them.  (Measured on the benchmark's clustered workload, scripts/query_order_purity.py: 1.5 clusters per
+//                32-row wave; 31.8 in the generator's order, 1.24 at best; one pivot id alone needs 1024 pivots for that.)
 //   radix sort   of (key, row)  ->  perm: scan position -> row
 //   gather       the query-side operands (16-bit rows, three norms) into that order
 //
 // The re-rank maps a scan position back to its row (SelectProblem::perm), outputs stay in the caller's row order, bits unchanged.
-// It pays only where rows have near-duplicates: order_keys also counts the rows within cosine 0.98 of their pivot, and the
-// host applies the order when there are several times more of them than pivots (Gaussian rows: exactly the pivots themselves).
+// It pays only where rows have near-duplicates: order_keys on a sample of the rows counts those within cosine 0.98 of a pivot
+// other than themselves, and the host applies the order when the estimate for all rows exceeds eight per pivot (Gaussian rows: none).
 // No reference counterpart: the reference materialises the N x N matrix (similarity_kernel.py:37-107) and has no scan.
 #include <hipcub/hipcub.hpp>
 
@@ -24,7 +26,7 @@
 
 namespace mmf {
 
-constexpr int QO_P = 256;          // pivots
+constexpr int QO_P = 128;          // pivots
 constexpr int QO_W = 8;            // waves per workgroup, 32 queries each
 constexpr int QO_KC = 64;          // k per staged chunk of the pivot rows
 constexpr int QO_LD = QO_KC + 8;   // 16-bit elements per LDS row (144 B: ds_read_b128 of 32 consecutive rows spreads over the banks)
@@ -37,6 +39,7 @@ struct OrderArgs {
   const uint16_t* ZQ; const float* q_zn; int64_t n;
   int dp;
   uint32_t* key; uint32_t* row; uint32_t* near_cnt;
+  int64_t wg_stride;       // workgroup b takes the 256 queries from 256 * b * wg_stride on (> 1: a sample, for the count alone)
 };
 
 __device__ __forceinline__ int64_t pivot_row(int j, int64_t m) { return ((int64_t)j * m) / QO_P; }
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(64 * QO_W) void order_keys_kernel(OrderArgs a) {
   __shared__ __attribute__((aligned(16))) uint16_t ptile[QO_P][QO_LD];
   __shared__ float pinv[QO_P];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int64_t q0 = ((int64_t)blockIdx.x * QO_W + w) * 32;
+  const int64_t q0 = ((int64_t)blockIdx.x * a.wg_stride * QO_W + w) * 32;
   if (tid < QO_P) {
     const float z = a.q_zn[pivot_row(tid, a.n)];
     pinv[tid] = z > 0.0f ? 1.0f / z : 0.0f;
@@ -59,9 +62,10 @@ __global__ __launch_bounds__(64 * QO_W) void order_keys_kernel(OrderArgs a) {
   // operand rows of this lane: query q0 + (lane & 31), k offset 8 (lane >> 5) inside a 16-wide step
   const uint16_t* qrow = a.ZQ + (q0 + (lane & 31)) * a.dp + 8 * (lane >> 5);
   for (int k0 = 0; k0 < a.dp; k0 += QO_KC) {
-    qo_u32x4 pv[4], qv[4];
+    constexpr int PU = QO_P * (QO_KC / 8) / (64 * QO_W);           // pivot rows x 8 units of 16 bytes, per thread
+    qo_u32x4 pv[PU], qv[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {                                   // 256 pivot rows x 8 units of 16 bytes
+    for (int i = 0; i < PU; ++i) {
       const int u = tid + 64 * QO_W * i;
       pv[i] = *reinterpret_cast<const qo_u32x4*>(a.ZQ + pivot_row(u >> 3, a.n) * a.dp + k0 + 8 * (u & 7));
     }
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(64 * QO_W) void order_keys_kernel(OrderArgs a) {
     for (int sx = 0; sx < 4; ++sx) qv[sx] = *reinterpret_cast<const qo_u32x4*>(qrow + k0 + 16 * sx);
     __syncthreads();                                                // the previous chunk has been read
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < PU; ++i) {
       const int u = tid + 64 * QO_W * i;
       *reinterpret_cast<qo_u32x4*>(&ptile[u >> 3][8 * (u & 7)]) = pv[i];
     }
@@ -87,20 +91,26 @@ __global__ __launch_bounds__(64 * QO_W) void order_keys_kernel(OrderArgs a) {
     }
   }
   // C layout: column (query) = lane & 31, row (pivot of the tile) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-  float best = -3.0e38f;
-  int bp = 0;
+  // nearest and second-nearest pivot (ties: the smaller pivot)
+  float best = -3.0e38f, sec = -3.0e38f;
+  int bp = 0, sp = 0;
 #pragma unroll
   for (int t = 0; t < QO_P / 32; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int p = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       const float v = acc[t][r] * pinv[p];
-      if (v > best) { best = v; bp = p; }
+      if (v > best) { sec = best; sp = bp; best = v; bp = p; }
+      else if (v > sec) { sec = v; sp = p; }
     }
   {
-    const float ob = __shfl_xor(best, 32);
-    const int op = __shfl_xor(bp, 32);
-    if (ob > best || (ob == best && op < bp)) { best = ob; bp = op; }
+    const float ob = __shfl_xor(best, 32), os = __shfl_xor(sec, 32);
+    const int op = __shfl_xor(bp, 32), osp = __shfl_xor(sp, 32);
+    const bool mine = best > ob || (best == ob && bp < op);          // this half's best wins
+    const float lb = mine ? ob : best; const int lp = mine ? op : bp;        // the losing best
+    const float ws = mine ? sec : os; const int wp = mine ? sp : osp;         // the winner's own second
+    if (!mine) { best = ob; bp = op; }
+    if (lb > ws || (lb == ws && lp < wp)) { sec = lb; sp = lp; } else { sec = ws; sp = wp; }
   }
   const int64_t q = q0 + (lane & 31);
   bool near = false;
@@ -108,12 +118,16 @@ __global__ __launch_bounds__(64 * QO_W) void order_keys_kernel(OrderArgs a) {
     const float zq = a.q_zn[q];
     float c = zq > 0.0f ? best / zq : 0.0f;
     c = c != c ? 0.0f : (c < -1.0f ? -1.0f : (c > 1.0f ? 1.0f : c));
-    near = c >= 0.98f;
-    a.key[q] = ((uint32_t)bp << 24) | (uint32_t)((c + 1.0f) * 8388607.5f);
-    a.row[q] = (uint32_t)q;
+    // a pivot row is its own nearest pivot: what counts as its near-duplicate is the second one
+    const float cn = (q == pivot_row(bp, a.n)) ? (zq > 0.0f ? sec / zq : 0.0f) : c;
+    near = cn >= 0.98f;
+    if (a.key) {
+      a.key[q] = ((uint32_t)bp << 25) | ((uint32_t)sp << 18) | (uint32_t)((c + 1.0f) * 131071.5f);
+      a.row[q] = (uint32_t)q;
+    }
   }
   const int nn = __popcll(__ballot(near));
-  if (lane == 0 && nn) atomicAdd(a.near_cnt + (blockIdx.x & 63), (uint32_t)nn);
+  if (lane == 0 && nn && a.near_cnt) atomicAdd(a.near_cnt + (blockIdx.x & 63), (uint32_t)nn);
 }
 
 // Query-side operands in scan order: position p takes row perm[p]; positions from n up to n_pad are zero rows.
@@ -140,6 +154,9 @@ __global__ __launch_bounds__(256) void order_gather_kernel(GatherArgs a) {
   *reinterpret_cast<qo_u32x4*>(a.Zo + pos * a.dp + 8 * part) = v;
 }
 
+static const int32_t* g_last_perm = nullptr;
+static int64_t g_last_perm_n = 0;
+
 static size_t order_sort_temp(int64_t n) {
   size_t tb = 0;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
@@ -153,36 +170,47 @@ size_t query_order_bytes(int64_t n) {
   return (4 * nn + 64) * 4 + order_sort_temp(n) + 256;
 }
 
-// Keys of all n query rows against 256 of them (the pivots); *near = rows within cosine 0.98 of their pivot.
-// Synchronises the stream (the caller decides on the host whether the order is worth applying).
-int launch_query_order_keys(const uint16_t* ZQ, const float* q_zn, int64_t n, int dp, bool f16, void* scratch, int64_t* near, hipStream_t s) {
-  if (n <= 0 || dp % QO_KC != 0) { set_error("query order: bad shape (n = %lld, dp = %d)", (long long)n, dp); return MMF_E_INTERNAL; }
-  const size_t nn = ((size_t)n + 63) & ~size_t(63);
-  uint32_t* o = static_cast<uint32_t*>(scratch);
-  OrderArgs a{ZQ, q_zn, n, dp, o, o + nn, o + 4 * nn};
-  MMF_HIP(hipMemsetAsync(a.near_cnt, 0, 256, s));
-  const int64_t grid = (n + 32 * QO_W - 1) / (32 * QO_W);
+static int launch_order_keys(bool f16, int64_t grid, hipStream_t s, const OrderArgs& a) {
   if (f16) hipLaunchKernelGGL(order_keys_kernel<true>, dim3((unsigned)grid), dim3(64 * QO_W), 0, s, a);
   else hipLaunchKernelGGL(order_keys_kernel<false>, dim3((unsigned)grid), dim3(64 * QO_W), 0, s, a);
   MMF_LAUNCH_CHECK();
+  return MMF_OK;
+}
+
+// Do the query rows have near-duplicates among themselves?  A sample of up to 32 blocks of 256 rows, spread over the rows, against the
+// pivot rows: *near = estimated number of rows within cosine 0.98 of a pivot row other than themselves.  Synchronises the
+// stream (the caller decides on the host whether the order is worth its 0.4 ms).
+int launch_query_order_probe(const uint16_t* ZQ, const float* q_zn, int64_t n, int dp, bool f16, void* scratch, int64_t* near, hipStream_t s) {
+  if (n <= 0 || dp % QO_KC != 0) { set_error("query order: bad shape (n = %lld, dp = %d)", (long long)n, dp); return MMF_E_INTERNAL; }
+  const size_t nn = ((size_t)n + 63) & ~size_t(63);
+  uint32_t* o = static_cast<uint32_t*>(scratch);
+  const int64_t wgs = (n + 32 * QO_W - 1) / (32 * QO_W);
+  const int64_t stride = wgs > 32 ? wgs / 32 : 1;
+  const int64_t grid = (wgs + stride - 1) / stride;
+  OrderArgs a{ZQ, q_zn, n, dp, nullptr, nullptr, o + 4 * nn, stride};
+  MMF_HIP(hipMemsetAsync(a.near_cnt, 0, 256, s));
+  MMF_TRY(launch_order_keys(f16, grid, s, a));
   uint32_t h[64];
   MMF_HIP(hipMemcpyAsync(h, a.near_cnt, 256, hipMemcpyDeviceToHost, s));
   MMF_HIP(hipStreamSynchronize(s));
-  int64_t tot = 0;
+  int64_t tot = 0, rows = 0;
   for (uint32_t v : h) tot += v;
-  *near = tot;
+  for (int64_t b = 0; b < grid; ++b) { const int64_t r0 = b * stride * 32 * QO_W; rows += (n - r0 < 32 * QO_W) ? (n - r0) : 32 * QO_W; }
+  *near = rows > 0 ? (int64_t)((double)tot * (double)n / (double)rows + 0.5) : 0;
   return MMF_OK;
 }
 
 int query_order_pivots() { return QO_P; }
 
-// Sorts the keys written by launch_query_order_keys and gathers the query side into that order.  *perm (device, n entries,
-// inside `scratch`): scan position -> row.
+// Keys of all rows, their sort, and the query side gathered into that order.  *perm (device, n entries, inside `scratch`): scan
+// position -> row.
 int launch_query_order_apply(const uint16_t* ZQ, const float* q_zn, const float* q_rn, const float* q_un, int64_t n, int64_t n_pad,
-                             int dp, void* scratch, uint16_t* Zo, float* zno, float* rno, float* uno, const int32_t** perm,
+                             int dp, bool f16, void* scratch, uint16_t* Zo, float* zno, float* rno, float* uno, const int32_t** perm,
                              hipStream_t s) {
   const size_t nn = ((size_t)n + 63) & ~size_t(63);
   uint32_t* o = static_cast<uint32_t*>(scratch);
+  OrderArgs a{ZQ, q_zn, n, dp, o, o + nn, nullptr, 1};
+  MMF_TRY(launch_order_keys(f16, (n + 32 * QO_W - 1) / (32 * QO_W), s, a));
   size_t tb = order_sort_temp(n);
   MMF_HIP(hipcub::DeviceRadixSort::SortPairs(o + 4 * nn + 64, tb, o, o + 2 * nn, o + nn, o + 3 * nn, (int)n, 0, 32, s));
   GatherArgs g{ZQ, q_zn, q_rn, q_un, o + 3 * nn, n, n_pad, dp, Zo, zno, rno, uno};
@@ -190,6 +218,14 @@ int launch_query_order_apply(const uint16_t* ZQ, const float* q_zn, const float*
   hipLaunchKernelGGL(order_gather_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, g);
   MMF_LAUNCH_CHECK();
   *perm = reinterpret_cast<const int32_t*>(o + 3 * nn);
+  g_last_perm = *perm; g_last_perm_n = n;
+  return MMF_OK;
+}
+
+// diagnostics (scripts/query_order_purity.py): the permutation of the most recent ordered call, while its workspace is alive
+int query_order_last(int32_t* out_host, int64_t n) {
+  if (!g_last_perm || n != g_last_perm_n) { set_error("query order: no permutation of %lld rows on record", (long long)n); return MMF_E_INVALID; }
+  MMF_HIP(hipMemcpy(out_host, g_last_perm, (size_t)n * 4, hipMemcpyDeviceToHost));
   return MMF_OK;
 }
 

@@ -502,7 +502,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
 // of once per query, and no lane walks a 512-long chain out of LDS.  A group whose union exceeds GR_PMAX columns (or a row
 // the lists could not serve) is left to the per-row pass behind this kernel (a.done stays 0).
 // ------------------------------------------------------------------------------------------------
-constexpr int GR_Q = 32, GR_PMAX = 384, GR_KC = 16, GR_MAXC = 224, GR_HASH = 1024, GR_LD = GR_KC + 1, GR_W = 8;
+constexpr int GR_Q = 32, GR_PMAX = 384, GR_KC = 16, GR_MAXC = 224, GR_HASH = 1024, GR_LD = GR_KC + 1, GR_W = 8, GR_AHEAD = 8;
 struct GroupLds {
   uint32_t cid[GR_Q][GR_MAXC];
   float ckey[GR_Q][GR_MAXC];
@@ -512,6 +512,9 @@ struct GroupLds {
   uint32_t hkey[GR_HASH];
   uint32_t hval[GR_HASH];
   uint32_t panel[GR_PMAX];
+  float pcy[GR_PMAX];
+  float qrx[GR_Q];
+  int qrow[GR_Q];
   int qpos[GR_Q];
   int qtot[GR_Q];
   int np;
@@ -534,11 +537,15 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
     if (slot < a.n_rows && a.key_sorted[slot] != 0xffffffffu) p = (int)a.row_sorted[slot];
     L.qpos[tid] = p;
     L.qtot[tid] = -1;
+    const int r = p < 0 ? -1 : (a.row_ids ? (int)a.row_ids[p] : p);       // list position -> row of X, and the row's scalar: fetched once,
+    L.qrow[tid] = r;                                                       // not as two dependent loads in front of every row's selection
+    L.qrx[tid] = r < 0 ? 0.0f : a.rx[r];
   }
   for (int i = tid; i < GR_HASH; i += 64 * GR_W) L.hkey[i] = 0xffffffffu;
   if (tid == 0) { L.np = 0; L.fail = 0; }
   __syncthreads();
-  if (L.qpos[0] < 0) return;                        // sorted order: nothing waits from here on
+  if (L.qpos[0] < 0) return;
+                        // sorted order: nothing waits from here on
   // Grouping pays when the rows of a group share their candidates — near-duplicate rows, which then carry the SAME key (the
   // smallest id of their common candidate set), so a group holds a few runs of equal keys.  Scattered rows with overflow
   // entries (Gaussian rows under bf16 operands) carry 32 different keys and share nothing: their union would overflow the
@@ -563,26 +570,34 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
     if (lane == 0) L.qtot[q] = total;
   }
   __syncthreads();
-  // (2) union of the candidates: id -> panel column
-  for (int q = 0; q < GR_Q; ++q) {
+  // (2) union of the candidates: id -> panel column.  Four rows at a time (128 threads each); the rows of a group mostly carry the
+  // same ids, so an entry is usually found by a plain read and the compare-and-swap is left to the first row that brings an id.
+  for (int it = 0; it < GR_Q / 4; ++it) {
+    const int q = 4 * it + (tid >> 7);
     const int total = L.qtot[q];
-    for (int e = tid; e < total; e += 64 * GR_W) {
+    for (int e = tid & 127; e < total; e += 128) {
       const uint32_t id = L.cid[q][e];
       if ((int64_t)id >= a.m) continue;
       uint32_t h = (id * 2654435761u) >> 22;
       for (int probe = 0; probe < GR_HASH; ++probe) {
-        if (*(volatile int*)&L.fail) break;
-        const uint32_t prev = atomicCAS(&L.hkey[h], 0xffffffffu, id);
-        if (prev == 0xffffffffu) {
-          const int idx = atomicAdd(&L.np, 1);
-          if (idx < GR_PMAX) { L.panel[idx] = id; L.hval[h] = (uint32_t)idx; } else L.fail = 1;
-          break;
-        }
+        uint32_t prev = *(volatile uint32_t*)&L.hkey[h];
         if (prev == id) break;
+        if (prev == 0xffffffffu) {
+          if (*(volatile int*)&L.fail) break;
+          prev = atomicCAS(&L.hkey[h], 0xffffffffu, id);
+          if (prev == 0xffffffffu) {
+            const int idx = atomicAdd(&L.np, 1);
+            if (idx < GR_PMAX) { L.panel[idx] = id; L.hval[h] = (uint32_t)idx; } else L.fail = 1;
+            break;
+          }
+          if (prev == id) break;
+        }
         h = (h + 1) & (GR_HASH - 1);
       }
     }
   }
+  __syncthreads();
+  if (!L.fail) for (int i = tid; i < L.np; i += 64 * GR_W) L.pcy[i] = a.cy[L.panel[i]];     // the columns' scalars, one gather for the group
   __syncthreads();
   if (L.fail) return;
   const int np = L.np;
@@ -592,8 +607,7 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
     const int nchunk = (int)((d + GR_KC - 1) / GR_KC);
     const bool qstage = tid < 128;                                    // query tile: 32 rows x 16 k = 128 16-byte pieces
     const int sq_row = (tid >> 2) & 31, sq_k = (tid & 3) * 4;
-    const int64_t qpos_s = L.qpos[sq_row] >= 0 ? (int64_t)L.qpos[sq_row] : (int64_t)L.qpos[0];
-    const int64_t qrow = a.row_ids ? (int64_t)a.row_ids[qpos_s] : qpos_s;
+    const int64_t qrow = L.qpos[sq_row] >= 0 ? (int64_t)L.qrow[sq_row] : (int64_t)L.qrow[0];
     const int c0 = pass * 32 * GR_W + 32 * w;
     const bool active = c0 < np;                                      // waves beyond the panel only keep the barriers
     int64_t prow[2];
@@ -606,47 +620,60 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    f32x4 qv = {0.f, 0.f, 0.f, 0.f}, pv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    auto gload = [&](int ch) {
+    // Global loads run GR_AHEAD chunks ahead of the matrix cores, in a ring of register stages (stage = chunk % GR_AHEAD): a chunk is
+    // 64 bytes of each gathered row, and with one chunk in flight every one of the d / 16 steps waited a full memory round trip.
+    f32x4 qv[GR_AHEAD], pv[GR_AHEAD][2];
+    auto gload = [&](int ch, f32x4& q_, f32x4 (&p_)[2]) {
       const int64_t k0 = (int64_t)ch * GR_KC;
-      if (qstage) {
-        qv = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (k0 + sq_k < d) qv = ld4_row<DT>(a.X, qrow * d + k0 + sq_k);
-      }
+      q_ = (f32x4){0.f, 0.f, 0.f, 0.f};
+      p_[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      p_[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (ch >= nchunk) return;
+      if (qstage && k0 + sq_k < d) q_ = ld4_row<DT>(a.X, qrow * d + k0 + sq_k);
       if (active) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          pv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (k0 + pk < d) pv[i] = ld4_row<DT>(a.Y, prow[i] * d + k0 + pk);
-        }
+        for (int i = 0; i < 2; ++i)
+          if (k0 + pk < d) p_[i] = ld4_row<DT>(a.Y, prow[i] * d + k0 + pk);
       }
     };
-    auto swrite = [&](int buf) {
+    auto swrite = [&](int buf, const f32x4& q_, const f32x4 (&p_)[2]) {
       if (qstage) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) L.qtile[buf][sq_row][sq_k + e] = qv[e];
+        for (int e = 0; e < 4; ++e) L.qtile[buf][sq_row][sq_k + e] = q_[e];
       }
       if (active) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) L.ptile[buf][w][(lane >> 2) + 16 * i][pk + e] = pv[i][e];
+          for (int e = 0; e < 4; ++e) L.ptile[buf][w][(lane >> 2) + 16 * i][pk + e] = p_[i][e];
       }
     };
-    gload(0);
-    swrite(0);
-    __syncthreads();
-    for (int ch = 0; ch < nchunk; ++ch) {
-      const int buf = ch & 1;
-      if (ch + 1 < nchunk) gload(ch + 1);
-      if (active) {
-        const float* qa = &L.qtile[buf][lane & 31][lane >> 5];
-        const float* pb = &L.ptile[buf][w][lane & 31][lane >> 5];
 #pragma unroll
-        for (int sx = 0; sx < GR_KC / 2; ++sx) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * sx], pb[2 * sx], acc, 0, 0, 0);
+    for (int j = 0; j < GR_AHEAD; ++j) gload(j, qv[j], pv[j]);
+    swrite(0, qv[0], pv[0]);
+    gload(GR_AHEAD, qv[0], pv[0]);
+    __syncthreads();
+    for (int base = 0; base < nchunk; base += GR_AHEAD) {
+#pragma unroll
+      for (int j = 0; j < GR_AHEAD; ++j) {
+        const int ch = base + j;                      // in LDS buffer ch & 1; chunk ch + 1 waits in stage (j + 1) % GR_AHEAD
+        if (ch < nchunk) {
+          const int buf = ch & 1;
+          if (active) {
+            const float* qa = &L.qtile[buf][lane & 31][lane >> 5];
+            const float* pb = &L.ptile[buf][w][lane & 31][lane >> 5];
+#pragma unroll
+            for (int sx = 0; sx < GR_KC / 2; ++sx) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * sx], pb[2 * sx], acc, 0, 0, 0);
+          }
+          constexpr int GR_AH = GR_AHEAD;
+          const int nx = (j + 1) % GR_AH;
+          if (ch + 1 < nchunk) {
+            swrite(buf ^ 1, qv[nx], pv[nx]);
+            gload(ch + 1 + GR_AHEAD, qv[nx], pv[nx]);
+          }
+          __syncthreads();
+        }
       }
-      if (ch + 1 < nchunk) swrite(buf ^ 1);
-      __syncthreads();
     }
     // C layout: column (candidate) = lane & 31, row (query) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     if (active) {
@@ -664,9 +691,9 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
     if (pos < 0 || total < 0) continue;
     uint32_t* id = L.cid[q];
     float* key = L.ckey[q];
-    const int64_t row = a.row_ids ? (int64_t)a.row_ids[pos] : (int64_t)pos;
+    const int64_t row = (int64_t)L.qrow[q];
     const int64_t grow = a.row_offset + row;
-    const float ri = a.rx[row];
+    const float ri = L.qrx[q];
     int valid = 0;
     for (int e = lane; e < total; e += 64) {
       const uint32_t j = id[e];
@@ -674,7 +701,8 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
       if ((int64_t)j < a.m && !(a.exclude_self && (a.col_offset + (int64_t)j == grow))) {
         uint32_t h = (j * 2654435761u) >> 22;
         while (L.hkey[h] != j) h = (h + 1) & (GR_HASH - 1);
-        kx = key_from_dot<METRIC>(L.dots[q][L.hval[h]], ri, a.cy[j], a.neg_lambda);
+        const uint32_t col = L.hval[h];
+        kx = key_from_dot<METRIC>(L.dots[q][col], ri, L.pcy[col], a.neg_lambda);
         if (kx != kx) kx = kNegInf;
         ++valid;
       } else {

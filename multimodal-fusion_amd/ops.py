@@ -74,6 +74,13 @@ def simtopk(X: torch.Tensor, Y: Optional[torch.Tensor] = None, *, metric="cosine
     return idx, val
 
 
+def last_query_order(n: int) -> torch.Tensor:
+    """Diagnostics: scan position -> row of the most recent simtopk call that reordered its n queries (mmf_debug_query_order)."""
+    out = torch.empty((n,), dtype=torch.int32)
+    _lib.check(_lib.lib().mmf_debug_query_order(ctypes.c_void_p(out.data_ptr()), ctypes.c_int64(n)), "mmf_debug_query_order")
+    return out
+
+
 def sim_dense(X: torch.Tensor, Y: Optional[torch.Tensor] = None, *, metric="rbf", lam: float = 1.0) -> torch.Tensor:
     X = _feat(X, "sim_dense X")
     _need_gpu(X, "sim_dense")
@@ -305,7 +312,7 @@ def prep_rows(X: torch.Tensor, metric, operand: str, scal: torch.Tensor, max_sq_
 def simtopk_prepared(X: torch.Tensor, Y: torch.Tensor, q: dict, c: dict, m_pad: int, maxima: torch.Tensor, *,
                      operand: str = "f16", metric="cosine", lam: float = 1.0, k: int = 5, exclude_self: bool = True,
                      row_offset: int = 0, col_offset: int = 0, profile: bool = False, col_splits: int = 0,
-                     wait_event: Optional[torch.cuda.Event] = None, return_stats: bool = False):
+                     wait_event: Optional[torch.cuda.Event] = None, return_stats: bool = False, query_order: str = "auto"):
     """Scan on prepared operands + exact re-rank (mmf_simtopk_prepared).  q / c: dicts with the tensors
     Z, scal, zn, rn, un, cb of the query / candidate side.  wait_event: recorded when the f32 rows of
     X / Y are complete; the stream waits for it only after the scan."""
@@ -319,7 +326,7 @@ def simtopk_prepared(X: torch.Tensor, Y: torch.Tensor, q: dict, c: dict, m_pad: 
         return _lib.PreparedSide(*(ctypes.c_void_p(dd[key].data_ptr()) for key in ("Z", "scal", "zn", "rn", "un", "cb")))
     qs, cs = side(q), side(c)
     ev = ctypes.c_void_p(wait_event.cuda_event) if wait_event is not None else None
-    opts = _lib.SimtopkOpts(_lib.PRECISIONS["fast"], int(profile), int(col_splits), 0, ev)
+    opts = _lib.SimtopkOpts(_lib.PRECISIONS["fast"], int(profile), int(col_splits), _lib.QUERY_ORDERS[query_order], ev)
     stats = _lib.SimtopkStats()
     rc = _lib.lib().mmf_simtopk_prepared(_p(X), n, _p(Y), m, d, _DT[X.dtype], _metric(metric), float(lam), int(k),
                                          int(bool(exclude_self)), int(row_offset), int(col_offset), ctypes.byref(qs),
@@ -334,7 +341,7 @@ def simtopk_prepared(X: torch.Tensor, Y: torch.Tensor, q: dict, c: dict, m_pad: 
 def simtopk_panels(X: torch.Tensor, Y: torch.Tensor, q: dict, c_scal: torch.Tensor, panels: list, maxima: torch.Tensor, *,
                    operand: str = "f16", metric="cosine", lam: float = 1.0, k: int = 5, exclude_self: bool = True,
                    row_offset: int = 0, col_offset: int = 0, profile: bool = False, col_splits: int = 0,
-                   wait_event: Optional[torch.cuda.Event] = None, return_stats: bool = False):
+                   wait_event: Optional[torch.cuda.Event] = None, return_stats: bool = False, query_order: str = "auto"):
     """Paneled scan + exact re-rank (mmf_simtopk_panels).  panels: dicts with Z [m_pad+256, dp], cb [m_pad+256], m,
     m_pad, and optionally seg_len / seg_stride / id_base (panel column -> column of Y) and `event` (a
     torch.cuda.Event the scan of that panel waits for).  q: query-side dict as for simtopk_prepared."""
@@ -351,7 +358,7 @@ def simtopk_panels(X: torch.Tensor, Y: torch.Tensor, q: dict, c_scal: torch.Tens
                             int(pn["m_pad"]), int(pn.get("seg_len", 0)), int(pn.get("seg_stride", 0)),
                             int(pn.get("id_base", 0)), ctypes.c_void_p(ev.cuda_event) if ev is not None else None)
     ev = ctypes.c_void_p(wait_event.cuda_event) if wait_event is not None else None
-    opts = _lib.SimtopkOpts(_lib.PRECISIONS["fast"], int(profile), int(col_splits), 0, ev)
+    opts = _lib.SimtopkOpts(_lib.PRECISIONS["fast"], int(profile), int(col_splits), _lib.QUERY_ORDERS[query_order], ev)
     stats = _lib.SimtopkStats()
     rc = _lib.lib().mmf_simtopk_panels(_p(X), n, _p(Y), m, d, _DT[X.dtype], _metric(metric), float(lam), int(k),
                                        int(bool(exclude_self)), int(row_offset), int(col_offset), ctypes.byref(qs),

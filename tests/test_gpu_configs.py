@@ -175,9 +175,11 @@ def test_phase_api_equals_single_call(mmf, metric):
         q = dict(Z=Z[lo:], **{n_: side[n_][lo:] for n_ in side})
         ev = torch.cuda.Event()
         ev.record()
-        i, v, st = ops.simtopk_prepared(X[lo:hi], X, q, dict(Z=Z, **side), m_pad, max4, metric=metric, k=k,
-                                        exclude_self=True, row_offset=lo, wait_event=ev, return_stats=True)
-        assert torch.equal(i, full_i[lo:hi]) and torch.equal(v, full_v[lo:hi]), (metric, r)
+        for order in ("off", "on"):                       # the scan's query order (csrc/mmf_order.hip) changes nothing
+            i, v, st = ops.simtopk_prepared(X[lo:hi], X, q, dict(Z=Z, **side), m_pad, max4, metric=metric, k=k,
+                                            exclude_self=True, row_offset=lo, wait_event=ev, return_stats=True, query_order=order)
+            assert st["query_order"] == (order == "on")
+            assert torch.equal(i, full_i[lo:hi]) and torch.equal(v, full_v[lo:hi]), (metric, r, order)
 
 
 @pytest.mark.parametrize("metric,S,splits", [("cosine", 4, 0), ("neg_sq_l2", 2, 4), ("dot", 1, 8), ("rbf", 4, 1)])
@@ -219,13 +221,15 @@ def test_paneled_scan_equals_single_call(mmf, metric, S, splits):
     for r in (0, 3):
         lo, hi = r * rows, (r + 1) * rows
         q = dict(Z=Z[lo:], scal=scal[lo:], zn=zn[lo:], rn=rn[lo:], un=un[lo:], cb=cb[lo:])
-        i, v, st = ops.simtopk_panels(X[lo:hi], X, q, scal, panels, max4, metric=metric, lam=0.5, k=k, exclude_self=True,
-                                      row_offset=lo, col_splits=splits, return_stats=True)
-        assert torch.equal(i, full_i[lo:hi]), (metric, r)
-        if metric == "rbf":
-            assert torch.allclose(v, full_v[lo:hi], rtol=0, atol=1e-5)
-        else:
-            assert torch.equal(v, full_v[lo:hi]), (metric, r)
+        for order in ("off", "on"):
+            i, v, st = ops.simtopk_panels(X[lo:hi], X, q, scal, panels, max4, metric=metric, lam=0.5, k=k, exclude_self=True,
+                                          row_offset=lo, col_splits=splits, return_stats=True, query_order=order)
+            assert st["query_order"] == (order == "on")
+            assert torch.equal(i, full_i[lo:hi]), (metric, r, order)
+            if metric == "rbf":
+                assert torch.allclose(v, full_v[lo:hi], rtol=0, atol=1e-5)
+            else:
+                assert torch.equal(v, full_v[lo:hi]), (metric, r, order)
     with pytest.raises(ValueError):
         bad = [dict(panels[0], m=m_c - seg)] + panels[1:]                      # panels no longer cover Y
         ops.simtopk_panels(X[:rows], X, q, scal, bad, max4, metric=metric, lam=0.5, k=k)
