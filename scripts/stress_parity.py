@@ -1,6 +1,6 @@
 """One-off stress: many seeded random configurations of mmf_simtopk against the CPU oracle (the shapes of
 tests/test_gpu_properties.py::test_random_configurations_against_the_oracle, with k up to 43, all precisions, clustered
-rows, more cases).  scripts/stress_parity.py [cases] [seed]"""
+rows, the scan's query order forced on in half of the cases, more cases).  scripts/stress_parity.py [cases] [seed]"""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, '.')
@@ -22,6 +22,7 @@ for case in range(cases):
     ro, co = int(rng.randint(0, 50)), int(rng.randint(0, 50))
     splits = int(rng.choice([0, 0, 1, 2, 8]))
     prec = str(rng.choice(["auto", "auto", "exact", "fast", "fast_bf16"]))
+    order = str(rng.choice(["on", "off"]))
     k = min(k, m - 1)
     if prec in ("fast", "fast_bf16") and not mmf.ops.fast_scan_supported(d, k, excl):
         prec = "auto"
@@ -39,9 +40,9 @@ for case in range(cases):
         Y[: min(n, m)] = X[: min(n, m)]                     # exact ties, self columns
     try:
         idx, val = mmf.simtopk(X, Y, metric=metric, lam=0.7, k=k, exclude_self=excl, row_offset=ro, col_offset=co,
-                               col_splits=splits, precision=prec)
+                               col_splits=splits, precision=prec, query_order=order)
     except RuntimeError as e:
-        print("ERROR", case, n, m, d, k, metric, dt, excl, ro, co, splits, prec, kind, str(e)[:120], flush=True)
+        print("ERROR", case, n, m, d, k, metric, dt, excl, ro, co, splits, prec, order, kind, str(e)[:120], flush=True)
         bad += 1
         continue
     ri, rv = oracle.simtopk(X.float().cpu().numpy(), Y.float().cpu().numpy(), metric=metric, lam=0.7, k=k,
@@ -50,7 +51,7 @@ for case in range(cases):
                                                      else np.array_equal(val.cpu().numpy(), rv))
     if not ok:
         bad += 1
-        print("MISMATCH", case, n, m, d, k, metric, dt, excl, ro, co, splits, prec, kind, flush=True)
+        print("MISMATCH", case, n, m, d, k, metric, dt, excl, ro, co, splits, prec, order, kind, flush=True)
     if case % 50 == 49:
         print(f"{case + 1} cases, {bad} bad, {time.time() - t0:.0f} s", flush=True)
 print("STRESS", "OK" if bad == 0 else f"FAILED ({bad})", cases, "cases")
