@@ -210,6 +210,13 @@ struct LaneList {
 #ifndef MMF_SINK_CHUNK
 #define MMF_SINK_CHUNK 8u      // A/B switches of scripts/ab_build.sh: -DMMF_SINK_CHUNK=1u, -DMMF_BAND_DIRECT=0
 #endif
+// A crowded list sends a hit to the overflow list not only below the proven k-th best key (`tband`) but up to a quarter of the margin
+// above it: pushing such a hit could raise the threshold by less than that quarter, while on near-duplicate data (a cluster's
+// cosines differ by 5e-5, the margin is 1e-3) every later member of the cluster lies just above `tband` and each push ends in a
+// wave-wide compaction sooner or later.  The band a row writes down becomes at most a quarter wider.  -DMMF_BAND_SLACK=0.0f: A/B.
+#ifndef MMF_BAND_SLACK
+#define MMF_BAND_SLACK 0.25f
+#endif
 #ifndef MMF_BAND_DIRECT
 #define MMF_BAND_DIRECT 1
 #endif
@@ -471,7 +478,7 @@ struct SlotList {
       rmask &= rmask - 1;
       const float x = v[r];
       bool hit = x >= thr;
-      const bool band = MMF_BAND_DIRECT && x < tband;
+      const bool band = MMF_BAND_DIRECT && x < tband + MMF_BAND_SLACK * margin;
       if (__any(hit && !band && cnt >= CAP)) {
         compact(kk, margin);
         hit = x >= thr;
