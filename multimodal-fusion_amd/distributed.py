@@ -147,7 +147,7 @@ def _pick_chunks(rows: int, world: int, chunks: Optional[int], own_first: bool =
 
 
 def _overlapped_simtopk(x_local, n_total, lo, hi, world, *, metric, lam, k, exclude_self, operand, group, return_stats,
-                        chunks=None, col_splits=0, own_first=None):
+                        chunks=None, col_splits=0, own_first=None, query_order="auto"):
     """Pipelined phase path.  Each rank prepares the 16-bit operands of its own rows and the ranks
     exchange them in S chunks (chunk c = rows [c*rows/S, (c+1)*rows/S) of every rank) by asynchronous all-gathers.
 
@@ -236,7 +236,7 @@ def _overlapped_simtopk(x_local, n_total, lo, hi, world, *, metric, lam, k, excl
     q = dict(Z=z_l, scal=pack_l[0], zn=pack_l[1], rn=pack_l[2], un=pack_l[3], cb=pack_l[4])
     out = ops.simtopk_panels(x_local, full, q, c_scal, panels, max_all, operand=operand, metric=metric, lam=lam, k=k,
                              exclude_self=exclude_self, row_offset=lo, col_offset=0, wait_event=ev_full,
-                             col_splits=col_splits, profile=return_stats, return_stats=return_stats)
+                             col_splits=col_splits, profile=return_stats, return_stats=return_stats, query_order=query_order)
     if return_stats:
         out[2]["panels"] = len(panels)
         out[2]["own_first"] = bool(own_first)
@@ -262,8 +262,12 @@ def pick_driver(x_local: torch.Tensor, n_total: int, world: int, *, metric="cosi
 def sharded_simtopk(x_local: torch.Tensor, n_total: int, *, metric="cosine", lam: float = 1.0, k: int = 5,
                     exclude_self: bool = True, precision: str = "auto", group=None, gather_output: bool = False,
                     op: Optional[Callable] = None, return_stats: bool = False, overlap: Optional[bool] = None,
-                    chunks: Optional[int] = None, col_splits: int = 0, own_first: Optional[bool] = None):
+                    chunks: Optional[int] = None, col_splits: int = 0, own_first: Optional[bool] = None,
+                    query_order: str = "auto"):
     """Top-k of every local row against ALL n_total rows.
+
+    query_order ("auto" / "off" / "on"): the order in which a rank's scan takes ITS rows (csrc/mmf_order.hip; near-duplicate rows
+    next to each other, decided from a probe of the rank's own rows from 32768 rows per rank; never changes a result).
 
     x_local: this rank's [N_r, d] shard (rows shard_bounds(n_total, world, rank)).
     Returns (idx int64 [N_r, k] GLOBAL column ids, val f32 [N_r, k]); with gather_output the full
@@ -281,7 +285,7 @@ def sharded_simtopk(x_local: torch.Tensor, n_total: int, *, metric="cosine", lam
         out = _overlapped_simtopk(x_local.contiguous(), n_total, lo, hi, world, metric=metric, lam=lam, k=k,
                                   exclude_self=exclude_self, operand="bf16" if precision == "fast_bf16" else "f16",
                                   group=group, return_stats=return_stats, chunks=chunks, col_splits=col_splits,
-                                  own_first=own_first)
+                                  own_first=own_first, query_order=query_order)
         idx, val = out[0], out[1]
         if gather_output:
             idx = all_gather_rows(idx, n_total, group)
@@ -300,7 +304,7 @@ def sharded_simtopk(x_local: torch.Tensor, n_total: int, *, metric="cosine", lam
     kw = dict(metric=metric, lam=lam, k=k, exclude_self=exclude_self, row_offset=lo, col_offset=0)
     stats = None
     if op.__module__.endswith("ops"):
-        out = op(x_rows, full, precision=precision, return_stats=return_stats, profile=return_stats, **kw)
+        out = op(x_rows, full, precision=precision, return_stats=return_stats, profile=return_stats, query_order=query_order, **kw)
         if return_stats:
             idx, val, stats = out
         else:

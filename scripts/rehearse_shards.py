@@ -38,7 +38,8 @@ def rows(n, d, seed, scale, dt):
 
 def check(X, N, what, **kw):
     metric = kw.get("metric", "cosine")
-    ref_kw = {k: v for k, v in kw.items() if k in ("metric", "lam", "k", "precision")}
+    ref_kw = {k: v for k, v in kw.items() if k in ("metric", "lam", "k", "precision")}          # (the reference call: query order off)
+    ref_kw["query_order"] = "off"
     ref_i, ref_v = mmf.simtopk(X, **ref_kw)
     lo, hi = dmod.shard_bounds(N, world, rank)
     i, v, st = dmod.sharded_simtopk(X[lo:hi].clone(), N, return_stats=True, **kw)
@@ -98,6 +99,10 @@ assert st_c["candidates"] > 60 * (16384 // world), st_c      # the overflow list
 check(Xc, 16384, "clustered pipelined", metric="cosine", k=5, chunks=2)
 check(Xc, 16384, "clustered simple", metric="neg_sq_l2", k=5, overlap=False)
 check(Xc, 16384, "clustered k=24", metric="cosine", k=24, chunks=2)
+# ... and with every rank's scan taking its own rows in the near-duplicate order (csrc/mmf_order.hip; AUTO only tries it from 32768
+# rows per rank): the scan's list positions are then a permutation of the rank's rows, through both drivers
+check(Xc, 16384, "clustered pipelined, query order on", metric="cosine", k=5, chunks=2, query_order="on")
+check(Xc, 16384, "clustered simple, query order on", metric="neg_sq_l2", k=5, overlap=False, query_order="on")
 
 # uneven shards / exact precision take the simple driver
 X = make_rows(0, 8190 + world - 1, 128, dev)
