@@ -87,7 +87,7 @@ extern "C" {
 int         mmf_version(void);
 const char* mmf_last_error(void);
 /* diagnostics: the scan position -> row permutation of the most recent call that reordered its n queries (host buffer, n entries);
- * valid until the next call on that device / stream or mmf_release_workspaces.  MMF_E_INVALID when there is none. */
+ * valid until the next fast-path call or mmf_release_workspaces.  MMF_E_INVALID when there is none. */
 int         mmf_debug_query_order(int32_t* perm_host, int64_t n);
 
 /*

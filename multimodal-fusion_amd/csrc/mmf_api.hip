@@ -285,6 +285,7 @@ struct FastTail {
           int exclude_self, int64_t row_offset, int64_t col_offset, const FastOperands& fo_in, int64_t* out_idx,
           float* out_val, bool profile, void* select_wait_event, mmf_simtopk_stats* stats, int precision, hipStream_t s) {
     FastOperands fo = fo_in;
+    query_order_forget();
     EventTimer t_order;
     int64_t near_rows = -1;
     if (order_try) {
@@ -453,6 +454,7 @@ const char* mmf_last_error(void) { return g_err; }
 
 int mmf_release_workspaces(void) {
   std::lock_guard<std::mutex> lk(g_ws_mu);
+  query_order_forget();
   for (auto& slot : g_ws) {
     for (auto& kv : slot) {
       if (kv.second.base) {

@@ -163,6 +163,7 @@ size_t select_order_bytes(int64_t n);
 size_t query_order_bytes(int64_t n);
 int query_order_pivots();
 int query_order_last(int32_t* out_host, int64_t n);
+void query_order_forget();   // the recorded permutation is gone (a new fast-path call has begun, or the workspaces were released)
 int launch_query_order_probe(const uint16_t* ZQ, const float* q_zn, int64_t n, int dp, bool f16, void* scratch, int64_t* near, hipStream_t s);
 int launch_query_order_apply(const uint16_t* ZQ, const float* q_zn, const float* q_rn, const float* q_un, int64_t n, int64_t n_pad,
                              int dp, bool f16, void* scratch, uint16_t* Zo, float* zno, float* rno, float* uno, const int32_t** perm,

@@ -222,6 +222,8 @@ int launch_query_order_apply(const uint16_t* ZQ, const float* q_zn, const float*
   return MMF_OK;
 }
 
+void query_order_forget() { g_last_perm = nullptr; g_last_perm_n = 0; }
+
 // diagnostics (scripts/query_order_purity.py): the permutation of the most recent ordered call, while its workspace is alive
 int query_order_last(int32_t* out_host, int64_t n) {
   if (!g_last_perm || n != g_last_perm_n) { set_error("query order: no permutation of %lld rows on record", (long long)n); return MMF_E_INVALID; }

@@ -96,3 +96,20 @@ def test_auto_decides_from_the_data(mmf):
     assert small[2]["query_order"] == 0 and small[2]["near_rows"] == -1
     with pytest.raises(KeyError):
         mmf.simtopk(Xg[:100], k=3, query_order="sometimes")
+
+
+def test_the_recorded_permutation(mmf):
+    """mmf_debug_query_order: scan position -> row of the last ordered call is a permutation that puts the copies of a row next to
+    each other; it is forgotten by the next fast-path call."""
+    rng = np.random.RandomState(9)
+    base = rng.randn(50, 48).astype(np.float32)
+    lab = rng.randint(0, 50, 4000)
+    X = torch.from_numpy(base[lab] + 1e-4 * rng.randn(4000, 48).astype(np.float32)).cuda()
+    mmf.simtopk(X, metric="cosine", k=3, precision="fast", query_order="on")
+    perm = mmf.ops.last_query_order(4000).numpy()
+    assert np.array_equal(np.sort(perm), np.arange(4000))
+    runs = 1 + int((lab[perm][1:] != lab[perm][:-1]).sum())
+    assert runs <= 3 * 50, runs                    # 50 groups of ~80 copies: a few runs each (4000 in row order)
+    mmf.simtopk(X, metric="cosine", k=3, precision="fast", query_order="off")
+    with pytest.raises(ValueError):
+        mmf.ops.last_query_order(4000)
