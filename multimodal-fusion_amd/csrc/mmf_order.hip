@@ -29,6 +29,11 @@ namespace mmf {
 constexpr int QO_P = 128;          // pivots
 constexpr int QO_W = 8;            // waves per workgroup, 32 queries each
 constexpr int QO_KC = 64;          // k per staged chunk of the pivot rows
+// cosine from which a row counts as a near-duplicate of a pivot row.  The order pays when a row's margin band is its cluster; on looser
+// clusters it COSTS (scripts/query_order_loose.py, N = 262144 in 2048 clusters: cosines inside a cluster 0.999 / 0.99: scan 72 -> 54 /
+// 71 -> 61 ms; 0.92 / 0.8: 54.6 -> 56.7 / 54.2 -> 55.9 ms — a workgroup's 256 queries then share their busy stretches of the column
+// stream instead of averaging them out), so the probe asks for near-DUPLICATES, not for neighbours.
+constexpr float QO_NEAR = 0.98f;
 constexpr int QO_LD = QO_KC + 8;   // 16-bit elements per LDS row (144 B: ds_read_b128 of 32 consecutive rows spreads over the banks)
 
 typedef __bf16 qo_bf16x8 __attribute__((ext_vector_type(8)));
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(64 * QO_W) void order_keys_kernel(OrderArgs a) {
     c = c != c ? 0.0f : (c < -1.0f ? -1.0f : (c > 1.0f ? 1.0f : c));
     // a pivot row is its own nearest pivot: what counts as its near-duplicate is the second one
     const float cn = (q == pivot_row(bp, a.n)) ? (zq > 0.0f ? sec / zq : 0.0f) : c;
-    near = cn >= 0.98f;
+    near = cn >= QO_NEAR;
     if (a.key) {
       a.key[q] = ((uint32_t)bp << 25) | ((uint32_t)sp << 18) | (uint32_t)((c + 1.0f) * 131071.5f);
       a.row[q] = (uint32_t)q;
