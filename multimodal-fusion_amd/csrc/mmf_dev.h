@@ -210,12 +210,14 @@ struct LaneList {
 #ifndef MMF_SINK_CHUNK
 #define MMF_SINK_CHUNK 8u      // A/B switches of scripts/ab_build.sh: -DMMF_SINK_CHUNK=1u, -DMMF_BAND_DIRECT=0
 #endif
-// A crowded list sends a hit to the overflow list not only below the proven k-th best key (`tband`) but up to a quarter of the margin
-// above it: pushing such a hit could raise the threshold by less than that quarter, while on near-duplicate data (a cluster's
-// cosines differ by 5e-5, the margin is 1e-3) every later member of the cluster lies just above `tband` and each push ends in a
-// wave-wide compaction sooner or later.  The band a row writes down becomes at most a quarter wider.  -DMMF_BAND_SLACK=0.0f: A/B.
+// A crowded list sends a hit to the overflow list not only below the proven k-th best key (`tband`) but up to one margin above it:
+// pushing such a hit could raise the threshold by less than that margin, while on near-duplicate data (a cluster's cosines differ
+// by 5e-5 .. 2e-3, the margin is 1e-3) every later member of the cluster lies just above `tband` and each push ends in a wave-wide
+// compaction sooner or later.  The band a row writes down becomes at most twice as wide (measured: 129 -> 129 candidates per row on
+// the bench's clusters, 94 -> 106 on clusters with cosines 0.99; a quarter margin: 57.6 -> 53.6 ms / 60.5 -> 59.2 ms of scan, one
+// margin: 53.6 / 57.5 ms, four margins: the same).  -DMMF_BAND_SLACK=0.0f: A/B.
 #ifndef MMF_BAND_SLACK
-#define MMF_BAND_SLACK 0.25f
+#define MMF_BAND_SLACK 1.0f
 #endif
 #ifndef MMF_BAND_DIRECT
 #define MMF_BAND_DIRECT 1

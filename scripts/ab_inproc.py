@@ -22,10 +22,17 @@ ap.add_argument("--prec", default="fast")
 ap.add_argument("--data", default="gaussian")
 ap.add_argument("--topk", type=int, default=5)
 ap.add_argument("--half", action="store_true", help="fp16 features")
+ap.add_argument("--noise", type=float, default=0.0, help="> 0: 2048 clusters with this noise norm (scripts/query_order_loose.py) instead of --data")
 ap.add_argument("names", nargs="+")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 X = make_rows(0, a.rows, a.dim, dev, data=a.data)
+if a.noise > 0:
+    g = torch.Generator(device=dev).manual_seed(11)
+    centers = torch.randn((2048, a.dim), generator=g, device=dev)
+    centers = centers / centers.norm(dim=1, keepdim=True)
+    X = centers[torch.randint(0, 2048, (a.rows,), generator=g, device=dev)] + (a.noise / a.dim ** 0.5) * torch.randn((a.rows, a.dim), generator=g, device=dev)
+    X = X / X.norm(dim=1, keepdim=True)
 if a.half:
     X = X.half()
 
@@ -40,6 +47,7 @@ def use(name):
 
 
 libs, times, rerank, ref = {}, {n: [] for n in a.names}, {n: [] for n in a.names}, None
+cands, flagged = {}, {}
 for r in range(a.rounds + 1):
     for n in a.names:
         use(n)
@@ -50,10 +58,11 @@ for r in range(a.rounds + 1):
             else:
                 assert torch.equal(i, ref[0]) and torch.equal(v, ref[1]), f"{n}: result differs from {a.names[0]}"
             continue
+        cands[n], flagged[n] = st["candidates"] / a.rows, st["fallback_rows"]
         times[n].append(st["scan_ms"])
         rerank[n].append(st["rerank_ms"])
 for n in a.names:
     t = times[n]
     print(f"{n:12s} scan_ms median {statistics.median(t):7.3f}  min {min(t):7.3f}  max {max(t):7.3f}   "
           f"frac(median) {2.0 * a.rows * a.rows * a.dim / (statistics.median(t) * 1e-3) / 2.5e15:.4f}   "
-          f"rerank_ms median {statistics.median(rerank[n]):6.3f}", flush=True)
+          f"rerank_ms median {statistics.median(rerank[n]):6.3f}   candidates/row {cands[n]:6.1f}  flagged {flagged[n]}", flush=True)
