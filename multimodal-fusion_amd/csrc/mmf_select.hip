@@ -39,6 +39,8 @@ struct SelectArgs {
   uint32_t* key_in; uint32_t* row_in;              // pass 0 writes
   const uint32_t* key_sorted; const uint32_t* row_sorted;   // pass 1 reads
   uint8_t* done;                                   // [n_rows] rows the grouped re-rank (rerank_group_kernel) has finished
+  int group_by_pos;                                // grouped re-rank: groups are 32 consecutive list positions (the scan took its queries with
+                                                   //   near-duplicate rows next to each other: is_perm) instead of 32 rows of the key order
   int only_if;                                     // second pass: 0 always; 1 / 2: only when the grouped kernel finished less / not less than half of the waiting rows
   uint32_t* defer_cnt;                             // [512] rows that wait for the second pass (select_keys_kernel) and, behind them, rows the
                                                    //       grouped kernel finished — each count spread over 256 words
@@ -502,11 +504,10 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
 // of once per query, and no lane walks a 512-long chain out of LDS.  A group whose union exceeds GR_PMAX columns (or a row
 // the lists could not serve) is left to the per-row pass behind this kernel (a.done stays 0).
 // ------------------------------------------------------------------------------------------------
-constexpr int GR_Q = 32, GR_PMAX = 384, GR_KC = 16, GR_MAXC = 224, GR_HASH = 1024, GR_LD = GR_KC + 1, GR_W = 8, GR_AHEAD = 8;
+constexpr int GR_Q = 32, GR_PMAX = 512, GR_KC = 16, GR_MAXC = 224, GR_HASH = 1024, GR_LD = GR_KC + 1, GR_W = 8, GR_AHEAD = 8;
 struct GroupLds {
   uint32_t cid[GR_Q][GR_MAXC];
-  float ckey[GR_Q][GR_MAXC];
-  float dots[GR_Q][GR_PMAX + 1];
+  float dots[GR_Q][GR_PMAX + 1];       // before the matrix-core phase its first GR_Q x GR_MAXC floats hold the lists' approximate keys (gather_candidates' pruning)
   float qtile[2][GR_Q][GR_LD];
   float ptile[2][GR_W][32][GR_LD];
   uint32_t hkey[GR_HASH];
@@ -519,6 +520,7 @@ struct GroupLds {
   int qtot[GR_Q];
   int np;
   int fail;
+  int first;
 };
 
 template <int METRIC, int DT>
@@ -534,7 +536,10 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
   if (tid < GR_Q) {
     const int64_t slot = slot0 + tid;
     int p = -1;
-    if (slot < a.n_rows && a.key_sorted[slot] != 0xffffffffu) p = (int)a.row_sorted[slot];
+    if (slot < a.n_rows) {
+      if (a.group_by_pos) { if (a.overflow[slot] == 0 && a.spill_cnt[slot] != 0) p = (int)slot; }
+      else if (a.key_sorted[slot] != 0xffffffffu) p = (int)a.row_sorted[slot];
+    }
     L.qpos[tid] = p;
     L.qtot[tid] = -1;
     const int r = p < 0 ? -1 : (a.row_ids ? (int)a.row_ids[p] : p);       // list position -> row of X, and the row's scalar: fetched once,
@@ -544,14 +549,22 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
   for (int i = tid; i < GR_HASH; i += 64 * GR_W) L.hkey[i] = 0xffffffffu;
   if (tid == 0) { L.np = 0; L.fail = 0; }
   __syncthreads();
-  if (L.qpos[0] < 0) return;
-                        // sorted order: nothing waits from here on
+  if (tid < 64) {                                   // the rows of this group that wait, and the first of them (stand-in for the others)
+    const unsigned long long wait = __ballot(tid < GR_Q && L.qpos[tid < GR_Q ? tid : 0] >= 0);
+    if (tid == 0) {
+      L.first = wait ? __builtin_ctzll(wait) : -1;
+      // position order: nobody has counted the waiting rows yet (select_keys_kernel does it for the key order)
+      if (a.group_by_pos && wait) atomicAdd(a.defer_cnt + (blockIdx.x & 255), (uint32_t)__popcll(wait));
+    }
+  }
+  __syncthreads();
+  if (L.first < 0) return;                          // nothing waits here (key order: nor from here on)
   // Grouping pays when the rows of a group share their candidates — near-duplicate rows, which then carry the SAME key (the
   // smallest id of their common candidate set), so a group holds a few runs of equal keys.  Scattered rows with overflow
   // entries (Gaussian rows under bf16 operands) carry 32 different keys and share nothing: their union would overflow the
   // panel, and finding that out costs more than the per-row pass.  A group with more than four runs of keys is left alone.
   {
-    const bool change = tid > 0 && tid < GR_Q && L.qpos[tid] >= 0 && a.key_sorted[slot0 + tid] != a.key_sorted[slot0 + tid - 1];
+    const bool change = !a.group_by_pos && tid > 0 && tid < GR_Q && L.qpos[tid] >= 0 && a.key_sorted[slot0 + tid] != a.key_sorted[slot0 + tid - 1];
     if (tid < 64) { const int cnt = __popcll(__ballot(change)); if (tid == 0) L.fail = cnt; }
   }
   __syncthreads();
@@ -566,15 +579,29 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
     const int pos = L.qpos[q];
     if (pos < 0) continue;
     int total = -1;
-    if (a.overflow[pos] == 0) total = gather_candidates(a, pos, lane, L.cid[q], L.ckey[q], GR_MAXC);
+    if (a.overflow[pos] == 0) total = gather_candidates(a, pos, lane, L.cid[q], &L.dots[0][0] + q * GR_MAXC, GR_MAXC);
     if (lane == 0) L.qtot[q] = total;
   }
   __syncthreads();
+  // A group whose union does not fit the panel (rows of two or three clusters in one group) is taken as two halves of 16 rows, one
+  // after the other — half-empty matrix-core tiles, but still far cheaper than 32 per-row passes; a half that does not fit either is
+  // left to the per-row pass.
+  int nparts = 1;
+  bool fresh = true;
+  for (int part = 0; part < nparts; ++part) {
+  const int r0 = nparts == 1 ? 0 : (GR_Q / 2) * part, r1 = nparts == 1 ? GR_Q : r0 + GR_Q / 2;
+  if (!fresh) {
+    __syncthreads();
+    for (int i = tid; i < GR_HASH; i += 64 * GR_W) L.hkey[i] = 0xffffffffu;
+    if (tid == 0) { L.np = 0; L.fail = 0; }
+    __syncthreads();
+  }
+  fresh = false;
   // (2) union of the candidates: id -> panel column.  Four rows at a time (128 threads each); the rows of a group mostly carry the
   // same ids, so an entry is usually found by a plain read and the compare-and-swap is left to the first row that brings an id.
   for (int it = 0; it < GR_Q / 4; ++it) {
     const int q = 4 * it + (tid >> 7);
-    const int total = L.qtot[q];
+    const int total = (q >= r0 && q < r1) ? L.qtot[q] : -1;
     for (int e = tid & 127; e < total; e += 128) {
       const uint32_t id = L.cid[q][e];
       if ((int64_t)id >= a.m) continue;
@@ -599,7 +626,10 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
   __syncthreads();
   if (!L.fail) for (int i = tid; i < L.np; i += 64 * GR_W) L.pcy[i] = a.cy[L.panel[i]];     // the columns' scalars, one gather for the group
   __syncthreads();
-  if (L.fail) return;
+  if (L.fail) {
+    if (nparts == 1) { nparts = 2; part = -1; }     // again, as two halves
+    continue;
+  }
   const int np = L.np;
   // (3) all 32 x np canonical dots: in pass p wave w owns panel columns [256 p + 32 w, + 32)
   for (int pass = 0; pass * 32 * GR_W < np; ++pass) {
@@ -607,7 +637,7 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
     const int nchunk = (int)((d + GR_KC - 1) / GR_KC);
     const bool qstage = tid < 128;                                    // query tile: 32 rows x 16 k = 128 16-byte pieces
     const int sq_row = (tid >> 2) & 31, sq_k = (tid & 3) * 4;
-    const int64_t qrow = L.qpos[sq_row] >= 0 ? (int64_t)L.qrow[sq_row] : (int64_t)L.qrow[0];
+    const int64_t qrow = L.qpos[sq_row] >= 0 ? (int64_t)L.qrow[sq_row] : (int64_t)L.qrow[L.first];
     const int c0 = pass * 32 * GR_W + 32 * w;
     const bool active = c0 < np;                                      // waves beyond the panel only keep the barriers
     int64_t prow[2];
@@ -688,60 +718,67 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
     const int q = (GR_Q / GR_W) * w + qq;
     const int pos = L.qpos[q];
     const int total = L.qtot[q];
-    if (pos < 0 || total < 0) continue;
-    uint32_t* id = L.cid[q];
-    float* key = L.ckey[q];
+    if (pos < 0 || total < 0 || q < r0 || q >= r1) continue;
+    const uint32_t* id = L.cid[q];
     const int64_t row = (int64_t)L.qrow[q];
     const int64_t grow = a.row_offset + row;
     const float ri = L.qrx[q];
+    // a lane keeps its (up to four) candidates in registers: exact key and id, kNoIdx once taken or inadmissible
+    constexpr int GR_E = (GR_MAXC + 63) / 64;
+    float kx[GR_E];
+    uint32_t jx[GR_E];
     int valid = 0;
-    for (int e = lane; e < total; e += 64) {
-      const uint32_t j = id[e];
-      float kx = kNegInf;
-      if ((int64_t)j < a.m && !(a.exclude_self && (a.col_offset + (int64_t)j == grow))) {
-        uint32_t h = (j * 2654435761u) >> 22;
-        while (L.hkey[h] != j) h = (h + 1) & (GR_HASH - 1);
-        const uint32_t col = L.hval[h];
-        kx = key_from_dot<METRIC>(L.dots[q][col], ri, L.pcy[col], a.neg_lambda);
-        if (kx != kx) kx = kNegInf;
-        ++valid;
-      } else {
-        id[e] = kNoIdx;
+#pragma unroll
+    for (int i = 0; i < GR_E; ++i) {
+      const int e = lane + 64 * i;
+      kx[i] = kNegInf;
+      jx[i] = kNoIdx;
+      if (e < total) {
+        const uint32_t j = id[e];
+        if ((int64_t)j < a.m && !(a.exclude_self && (a.col_offset + (int64_t)j == grow))) {
+          uint32_t h = (j * 2654435761u) >> 22;
+          while (L.hkey[h] != j) h = (h + 1) & (GR_HASH - 1);
+          const uint32_t col = L.hval[h];
+          float kv = key_from_dot<METRIC>(L.dots[q][col], ri, L.pcy[col], a.neg_lambda);
+          if (kv != kv) kv = kNegInf;
+          kx[i] = kv;
+          jx[i] = j;
+          ++valid;
+        }
       }
-      key[e] = kx;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) valid += __shfl_xor(valid, o);
     if (valid < a.k) continue;                      // short of candidates: the per-row pass reports the row
     if (a.cand_total && lane == 0) atomicAdd(a.cand_total + (blockIdx.x & 255), (uint32_t)total);
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
     for (int t = 0; t < a.k; ++t) {
       float bk = kNegInf;
       uint32_t bi = kNoIdx;
-      int be = -1;
-      for (int e = lane; e < total; e += 64) {
-        const uint32_t ie = id[e];
-        if (ie != kNoIdx && (be < 0 || better(key[e], ie, bk, bi))) { bk = key[e]; bi = ie; be = e; }
-      }
+      int bs = -1;                                  // lane + 64 * register slot of the best entry
+#pragma unroll
+      for (int i = 0; i < GR_E; ++i)
+        if (jx[i] != kNoIdx && (bs < 0 || better(kx[i], jx[i], bk, bi))) { bk = kx[i]; bi = jx[i]; bs = lane + 64 * i; }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
         const float ok2 = __shfl_xor(bk, o);
         const uint32_t oi = (uint32_t)__shfl_xor((int)bi, o);
-        const int oe = __shfl_xor(be, o);
-        const bool take = (oe >= 0) && (be < 0 || better(ok2, oi, bk, bi));
-        if (take) { bk = ok2; bi = oi; be = oe; }
+        const int os = __shfl_xor(bs, o);
+        const bool take = (os >= 0) && (bs < 0 || better(ok2, oi, bk, bi));
+        if (take) { bk = ok2; bi = oi; bs = os; }
       }
-      if (be >= 0 && (be & 63) == lane) id[be] = kNoIdx;
+      if (bs >= 0 && (bs & 63) == lane) {
+#pragma unroll
+        for (int i = 0; i < GR_E; ++i)
+          if (i == (bs >> 6)) jx[i] = kNoIdx;
+      }
       if (lane == 0) {
         a.out_idx[row * a.out_stride + a.out_off + t] = a.col_offset + (int64_t)bi;
         a.out_val[row * a.out_stride + a.out_off + t] = val_from_key<METRIC>(bk);
       }
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) { a.done[pos] = 1; atomicAdd(a.defer_cnt + 256 + (blockIdx.x & 255), 1u); }
   }
+  }   // parts
 }
 
 template <int METRIC>
@@ -767,15 +804,23 @@ static int launch_select_m(const SelectArgs& a, bool vec4, bool staged16, void* 
       MMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       int64_t g = grid;
       b.order_blocks = grid;
-      if (pass == 1 && a.key_in) {                    // order the waiting rows by their smallest candidate id
-        hipLaunchKernelGGL(select_keys_kernel, dim3((unsigned)((a.n_rows + 255) / 256)), dim3(256), 0, s, a);
-        MMF_LAUNCH_CHECK();
-        size_t tb = order_temp_bytes;
-        // keys are candidate ids < m, or 0xffffffff (not waiting): the low bits(m) + 1 bits order the ids and keep the marker last
-        int nb = 1;
-        while (nb < 32 && (int64_t(1) << (nb - 1)) < a.m) ++nb;
-        MMF_HIP(hipcub::DeviceRadixSort::SortPairs(order_temp, tb, a.key_in, const_cast<uint32_t*>(a.key_sorted), a.row_in,
-                                                   const_cast<uint32_t*>(a.row_sorted), (int)a.n_rows, 0, nb, s));
+      if (pass == 1 && a.key_in) {
+        if (a.is_perm) {
+          // the scan took its queries with near-duplicate rows next to each other: 32 consecutive list positions ARE rows that share
+          // their candidates, whatever the smallest id of each one's set (rows of a looser cluster hold different subsets of it, and
+          // the key order scatters them)
+          b.group_by_pos = 1;
+          b.key_sorted = nullptr; b.row_sorted = nullptr;
+        } else {                                      // order the waiting rows by their smallest candidate id
+          hipLaunchKernelGGL(select_keys_kernel, dim3((unsigned)((a.n_rows + 255) / 256)), dim3(256), 0, s, a);
+          MMF_LAUNCH_CHECK();
+          size_t tb = order_temp_bytes;
+          // keys are candidate ids < m, or 0xffffffff (not waiting): the low bits(m) + 1 bits order the ids and keep the marker last
+          int nb = 1;
+          while (nb < 32 && (int64_t(1) << (nb - 1)) < a.m) ++nb;
+          MMF_HIP(hipcub::DeviceRadixSort::SortPairs(order_temp, tb, a.key_in, const_cast<uint32_t*>(a.key_sorted), a.row_in,
+                                                     const_cast<uint32_t*>(a.row_sorted), (int)a.n_rows, 0, nb, s));
+        }
         g = (grid + 7) / 8 * 8;
         b.order_blocks = g;
         // grouped re-rank of 32 consecutive rows of that order on the matrix cores; what it leaves is done by the launch below

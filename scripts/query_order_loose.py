@@ -11,7 +11,7 @@ g = torch.Generator(device=dev).manual_seed(11)
 centers = torch.randn((C, d), generator=g, device=dev)
 centers = centers / centers.norm(dim=1, keepdim=True)
 assign = torch.randint(0, C, (N,), generator=g, device=dev)
-for noise in (0.1, 0.3, 0.5, 1.0):
+for noise in ([float(x) for x in sys.argv[1:]] or [0.1, 0.3, 0.5, 1.0]):
     X = centers[assign] + (noise / d ** 0.5) * torch.randn((N, d), generator=g, device=dev)
     X = X / X.norm(dim=1, keepdim=True)
     out = {}
