@@ -99,6 +99,8 @@ def main() -> None:
     ap.add_argument("--metric", default="cosine")
     ap.add_argument("--precision", default="auto", choices=["auto", "exact", "fast", "fast_bf16"])
     ap.add_argument("--data", default="gaussian", choices=["gaussian", "clustered"])
+    ap.add_argument("--query-order", default="auto", choices=["auto", "off", "on"],
+                    help="order in which the scan takes the query rows (csrc/mmf_order.hip); auto = the library's own decision")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-leg", action="store_true")
     ap.add_argument("--simple-driver", action="store_true", help="N > 1: one all-gather of the f32 shard, then one scan")
@@ -140,7 +142,7 @@ def main() -> None:
 
     def step(profile: bool, precision: str = args.precision):
         return dmod.sharded_simtopk(x_local, n, metric=args.metric, k=k, exclude_self=True, precision=precision,
-                                    return_stats=profile, overlap=overlap)
+                                    return_stats=profile, overlap=overlap, query_order=args.query_order)
 
     def fence():
         torch.cuda.synchronize()

@@ -136,6 +136,10 @@ __global__ __launch_bounds__(64 * QO_W) void order_keys_kernel(OrderArgs a) {
 }
 
 // Query-side operands in scan order: position p takes row perm[p]; positions from n up to n_pad are zero rows.
+// (Tried: dealing the sorted order out wave by wave, so that the eight waves of a workgroup come from eight distant stretches of it —
+// a wave has to be homogeneous, a workgroup need not be, and workgroups of like queries drift apart along the column stream: the
+// clustered bench workload shows 109 GB of L2 misses per scan launch instead of 9, `profiles/r03c_pmc_summary.json`.  It is slower,
+// 53.4 -> 54.4 ms: eight like waves are in the list code AT THE SAME tiles, so they wait for each other once, not eight times.)
 struct GatherArgs {
   const uint16_t* Z; const float* zn; const float* rn; const float* un;
   const uint32_t* perm; int64_t n, n_pad; int dp;
