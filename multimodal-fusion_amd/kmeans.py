@@ -17,6 +17,7 @@ are themselves reproducible only up to the decisions that rounding noise takes; 
 """
 from __future__ import annotations
 
+import functools
 import math
 from typing import Tuple
 
@@ -24,6 +25,16 @@ import numpy as np
 import torch
 
 from . import ops
+
+
+@functools.lru_cache(maxsize=4)
+def _uniform_cdf(n_samples: int) -> np.ndarray:
+    """cdf of RandomState.choice(n, p=ones(n, float32) / float32(n)): cumsum of the float32 weights in float64, normalised."""
+    p = (np.ones(n_samples, np.float32) / np.float32(n_samples)).astype(np.float64)
+    cdf = p.cumsum()
+    cdf /= cdf[-1]
+    cdf.setflags(write=False)
+    return cdf
 
 
 def sklearn_stream(seed: int, n_init: int, n_clusters: int, n_samples: int) -> Tuple[np.ndarray, np.ndarray]:
@@ -34,15 +45,14 @@ def sklearn_stream(seed: int, n_init: int, n_clusters: int, n_samples: int) -> T
     (side='right') in the normalised float64 cumulative sum of p (numpy/random/mtrand.pyx)."""
     trials = 2 + int(math.log(n_clusters))
     rs = np.random.RandomState(seed)
-    p = (np.ones(n_samples, np.float32) / np.float32(n_samples)).astype(np.float64)
-    cdf = p.cumsum()
-    cdf /= cdf[-1]
-    first = np.empty(n_init, np.int64)
-    u = np.empty((n_init, max(n_clusters - 1, 0), trials), np.float64)
-    for i in range(n_init):
-        first[i] = cdf.searchsorted(rs.random_sample(), side="right")
-        for c in range(n_clusters - 1):
-            u[i, c] = rs.uniform(size=trials)
+    cdf = _uniform_cdf(n_samples)
+    # per restart the stream gives one double for the first centre, then `trials` doubles per seeding step (uniform(size=trials) is
+    # 0.0 + 1.0 * the next doubles, bit for bit): ONE random_sample call yields the same doubles as scikit-learn's n_init * k calls
+    # (oracle/kmeans_restate.py keeps the call-by-call form; the GPU tests compare the seeds of both)
+    steps = max(n_clusters - 1, 0)
+    r = rs.random_sample(n_init * (1 + steps * trials)).reshape(n_init, 1 + steps * trials)
+    first = cdf.searchsorted(r[:, 0], side="right").astype(np.int64)
+    u = np.ascontiguousarray(r[:, 1:]).reshape(n_init, steps, trials)
     np.clip(first, 0, n_samples - 1, out=first)
     return first, u
 
