@@ -466,6 +466,25 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
   if (a.cand_total && lane == 0) atomicAdd(a.cand_total + (blockIdx.x & 255), (uint32_t)total);
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_wave_barrier();
+  if (total <= 64) {
+    // One candidate per lane (the usual row: two lane lists): every lane COUNTS the candidates that rank before its own — each one
+    // broadcast out of its lane's registers by v_readlane, no LDS trip, no butterfly — and the k lanes with ranks below k write the
+    // row's output themselves.  (key desc, id asc) is a strict total order on distinct ids, so the ranks are distinct.
+    const float mk = lane < total ? key[lane] : kNegInf;
+    const uint32_t mi = lane < total ? id[lane] : kNoIdx;
+    int rank = 0;
+    for (int e = 0; e < total; ++e) {
+      const float ke = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(mk), e));
+      const uint32_t ie = (uint32_t)__builtin_amdgcn_readlane((int)mi, e);
+      rank += (ie != kNoIdx && better(ke, ie, mk, mi)) ? 1 : 0;
+    }
+    if (mi != kNoIdx && rank < a.k) {
+      a.out_idx[row * a.out_stride + a.out_off + rank] = a.col_offset + (int64_t)mi;
+      a.out_val[row * a.out_stride + a.out_off + rank] = val_from_key<METRIC>(mk);
+      if (a.floor_key_out && rank == a.k - 1) { a.floor_key_out[pos] = mk; a.floor_id_out[pos] = mi; }
+    }
+    continue;
+  }
   for (int t = 0; t < a.k; ++t) {
     float bk = kNegInf;
     uint32_t bi = kNoIdx;

@@ -16,6 +16,8 @@ cent = rng.randn(200, 512).astype(np.float32)
 cases.append(("clustered N=65536", (cent[rng.randint(0, 200, 65536)] * 0.3 + 0.05 * rng.randn(65536, 512)).astype(np.float32), 100))
 S = np.exp(-0.05 * ((rng.randn(100, 1, 16) - rng.randn(1, 256, 16)) ** 2).sum(-1)).astype(np.float32)
 cases.append(("similarity rows 100 x 256, 10 groups", S, 10))
+if os.environ.get("ONLY"):
+    cases = [c for c in cases if os.environ["ONLY"] in c[0]]
 for tag, X, k in cases:
     Xg = torch.from_numpy(X).cuda()
     n = X.shape[0]
