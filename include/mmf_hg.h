@@ -134,7 +134,7 @@ typedef struct mmf_simtopk_stats {
                               ready_events (exposed exchange time), 0 otherwise                   */
   int64_t  overflow_rows;  /* fallback rows whose candidate list overflowed (near-ties beyond capacity) */
   int64_t  short_rows;     /* fallback rows whose lists held fewer than k admissible candidates   */
-  int64_t  near_rows;      /* estimated query rows within cosine 0.98 of one of 128 pivot rows other than themselves (-1: not probed) */
+  int64_t  near_rows;      /* estimated query rows within cosine 0.965 of one of 128 pivot rows other than themselves (-1: not probed) */
   float    order_ms;       /* profile = 1: pivot keys + sort + gather of the query order (0 when not tried)      */
   int      query_order;    /* 1: the scan took the queries with near-duplicate rows next to each other           */
 } mmf_simtopk_stats;

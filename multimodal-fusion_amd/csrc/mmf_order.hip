@@ -16,7 +16,7 @@
 //   gather       the query-side operands (16-bit rows, three norms) into that order
 //
 // The re-rank maps a scan position back to its row (SelectProblem::perm), outputs stay in the caller's row order, bits unchanged.
-// It pays only where rows have near-duplicates: order_keys on a sample of the rows counts those within cosine 0.98 of a pivot
+// It pays only where rows have near-duplicates: order_keys on a sample of the rows counts those within cosine 0.965 of a pivot
 // other than themselves, and the host applies the order when the estimate for all rows exceeds eight per pivot (Gaussian rows: none).
 // No reference counterpart: the reference materialises the N x N matrix (similarity_kernel.py:37-107) and has no scan.
 #include <hipcub/hipcub.hpp>
@@ -29,11 +29,11 @@ namespace mmf {
 constexpr int QO_P = 128;          // pivots
 constexpr int QO_W = 8;            // waves per workgroup, 32 queries each
 constexpr int QO_KC = 64;          // k per staged chunk of the pivot rows
-// cosine from which a row counts as a near-duplicate of a pivot row.  The order pays when a row's margin band is its cluster; on looser
-// clusters it COSTS (scripts/query_order_loose.py, N = 262144 in 2048 clusters: cosines inside a cluster 0.999 / 0.99: scan 72 -> 54 /
-// 71 -> 61 ms; 0.92 / 0.8: 54.6 -> 56.7 / 54.2 -> 55.9 ms — a workgroup's 256 queries then share their busy stretches of the column
-// stream instead of averaging them out), so the probe asks for near-DUPLICATES, not for neighbours.
-constexpr float QO_NEAR = 0.98f;
+// cosine from which a row counts as a near-duplicate of a pivot row.  The order pays when a row's margin band is (most of) its cluster; on
+// looser clusters it COSTS (scripts/query_order_loose.py, N = 262144 in 2048 clusters, scan + re-rank with the order off -> on, by the
+// cosine inside a cluster: 0.999: 73 -> 57 ms; 0.99: 74 -> 62; 0.978: 69 -> 62; 0.969: 63.6 -> 59.9; 0.962: 58.0 -> 58.5; 0.92: 56.2 -> 58.3;
+// 0.8: 55.5 -> 57.2), so the probe asks for near-DUPLICATES, not for neighbours.
+constexpr float QO_NEAR = 0.965f;
 constexpr int QO_LD = QO_KC + 8;   // 16-bit elements per LDS row (144 B: ds_read_b128 of 32 consecutive rows spreads over the banks)
 
 typedef __bf16 qo_bf16x8 __attribute__((ext_vector_type(8)));
@@ -187,7 +187,7 @@ static int launch_order_keys(bool f16, int64_t grid, hipStream_t s, const OrderA
 }
 
 // Do the query rows have near-duplicates among themselves?  A sample of up to 32 blocks of 256 rows, spread over the rows, against the
-// pivot rows: *near = estimated number of rows within cosine 0.98 of a pivot row other than themselves.  Synchronises the
+// pivot rows: *near = estimated number of rows within cosine 0.965 of a pivot row other than themselves.  Synchronises the
 // stream (the caller decides on the host whether the order is worth its 0.4 ms).
 int launch_query_order_probe(const uint16_t* ZQ, const float* q_zn, int64_t n, int dp, bool f16, void* scratch, int64_t* near, hipStream_t s) {
   if (n <= 0 || dp % QO_KC != 0) { set_error("query order: bad shape (n = %lld, dp = %d)", (long long)n, dp); return MMF_E_INTERNAL; }
