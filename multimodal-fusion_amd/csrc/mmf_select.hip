@@ -287,6 +287,32 @@ __device__ __forceinline__ f32x4 ld4_row(const void* base, int64_t elem) {
   }
 }
 
+// the same four elements as ld4_row, split into the memory operation and the conversion: a load whose result is converted at once is
+// waited for at once, and a ring of loads in flight needs the loads alone
+template <int DT> struct Raw4 { typedef uint2 type; };
+template <> struct Raw4<MMF_F32> { typedef f32x4 type; };
+template <int DT>
+__device__ __forceinline__ typename Raw4<DT>::type ld4_raw(const void* base, int64_t elem) {
+  if constexpr (DT == MMF_F32) return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + elem);
+  else return *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem);
+}
+template <int DT>
+__device__ __forceinline__ f32x4 cvt4_raw(const typename Raw4<DT>::type& u) {
+  if constexpr (DT == MMF_F32) {
+    return u;
+  } else {
+    f32x4 v;
+    if constexpr (DT == MMF_BF16) {
+      v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+      v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    } else {
+      v[0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u.x & 0xffffu)); v[1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u.x >> 16));
+      v[2] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u.y & 0xffffu)); v[3] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u.y >> 16));
+    }
+    return v;
+  }
+}
+
 // Sort keys of the ordered second pass, one wave per 64 rows: a row that waits for that pass (overflow-list entries, not flagged)
 // gets its smallest candidate id, every other row the marker 0xffffffff; the waiting rows are counted (spread over 256 words).
 // Kept out of the first pass's kernel, whose register count decides how many of its waves fit a SIMD.
@@ -671,57 +697,58 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     // Global loads run GR_AHEAD chunks ahead of the matrix cores, in a ring of register stages (stage = chunk % GR_AHEAD): a chunk is
     // 64 bytes of each gathered row, and with one chunk in flight every one of the d / 16 steps waited a full memory round trip.
-    f32x4 qv[GR_AHEAD], pv[GR_AHEAD][2];
-    auto gload = [&](int ch, f32x4& q_, f32x4 (&p_)[2]) {
-      const int64_t k0 = (int64_t)ch * GR_KC;
-      q_ = (f32x4){0.f, 0.f, 0.f, 0.f};
-      p_[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      p_[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (ch >= nchunk) return;
-      if (qstage && k0 + sq_k < d) q_ = ld4_row<DT>(a.X, qrow * d + k0 + sq_k);
-      if (active) {
+    // The loads are UNCONDITIONAL (clamped addresses; what lies outside the rows' d elements or past the last chunk is zeroed when it
+    // is written to LDS): a load under a branch, or one converted where it is issued, makes the compiler wait for everything in
+    // flight — s_waitcnt vmcnt(0) — at the next LDS write, and the ring held one chunk instead of eight.
+    typedef typename Raw4<DT>::type raw_t;
+    raw_t qv[GR_AHEAD], pv[GR_AHEAD][2];
+    auto gload = [&](int ch, raw_t& q_, raw_t (&p_)[2]) {
+      const int64_t k0 = (int64_t)(ch < nchunk ? ch : nchunk - 1) * GR_KC;
+      const int64_t kq = (k0 + sq_k < d) ? k0 + sq_k : d - 4, kp = (k0 + pk < d) ? k0 + pk : d - 4;
+      q_ = ld4_raw<DT>(a.X, qrow * d + kq);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-          if (k0 + pk < d) p_[i] = ld4_row<DT>(a.Y, prow[i] * d + k0 + pk);
-      }
+      for (int i = 0; i < 2; ++i) p_[i] = ld4_raw<DT>(a.Y, prow[i] * d + kp);
     };
-    auto swrite = [&](int buf, const f32x4& q_, const f32x4 (&p_)[2]) {
+    auto swrite = [&](int buf, int ch, const raw_t& q_, const raw_t (&p_)[2]) {
+      const int64_t k0 = (int64_t)ch * GR_KC;
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
       if (qstage) {
+        const f32x4 qf = (ch < nchunk && k0 + sq_k < d) ? cvt4_raw<DT>(q_) : zero;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) L.qtile[buf][sq_row][sq_k + e] = q_[e];
+        for (int e = 0; e < 4; ++e) L.qtile[buf][sq_row][sq_k + e] = qf[e];
       }
       if (active) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+          const f32x4 pf = (ch < nchunk && k0 + pk < d) ? cvt4_raw<DT>(p_[i]) : zero;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) L.ptile[buf][w][(lane >> 2) + 16 * i][pk + e] = p_[i][e];
+          for (int e = 0; e < 4; ++e) L.ptile[buf][w][(lane >> 2) + 16 * i][pk + e] = pf[e];
+        }
       }
     };
 #pragma unroll
     for (int j = 0; j < GR_AHEAD; ++j) gload(j, qv[j], pv[j]);
-    swrite(0, qv[0], pv[0]);
+    swrite(0, 0, qv[0], pv[0]);
     gload(GR_AHEAD, qv[0], pv[0]);
     __syncthreads();
+    // (the loop runs whole rounds of GR_AHEAD steps: past the last chunk a step only writes zeros and issues a clamped load, so that
+    //  NO memory operation sits under a branch and the compiler can wait for a stage with a counted vmcnt instead of vmcnt(0))
     for (int base = 0; base < nchunk; base += GR_AHEAD) {
 #pragma unroll
       for (int j = 0; j < GR_AHEAD; ++j) {
         const int ch = base + j;                      // in LDS buffer ch & 1; chunk ch + 1 waits in stage (j + 1) % GR_AHEAD
-        if (ch < nchunk) {
-          const int buf = ch & 1;
-          if (active) {
-            const float* qa = &L.qtile[buf][lane & 31][lane >> 5];
-            const float* pb = &L.ptile[buf][w][lane & 31][lane >> 5];
+        const int buf = ch & 1;
+        if (active && ch < nchunk) {
+          const float* qa = &L.qtile[buf][lane & 31][lane >> 5];
+          const float* pb = &L.ptile[buf][w][lane & 31][lane >> 5];
 #pragma unroll
-            for (int sx = 0; sx < GR_KC / 2; ++sx) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * sx], pb[2 * sx], acc, 0, 0, 0);
-          }
-          constexpr int GR_AH = GR_AHEAD;
-          const int nx = (j + 1) % GR_AH;
-          if (ch + 1 < nchunk) {
-            swrite(buf ^ 1, qv[nx], pv[nx]);
-            gload(ch + 1 + GR_AHEAD, qv[nx], pv[nx]);
-          }
-          __syncthreads();
+          for (int sx = 0; sx < GR_KC / 2; ++sx) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * sx], pb[2 * sx], acc, 0, 0, 0);
         }
+        constexpr int GR_AH = GR_AHEAD;
+        const int nx = (j + 1) % GR_AH;
+        swrite(buf ^ 1, ch + 1, qv[nx], pv[nx]);
+        gload(ch + 1 + GR_AHEAD, qv[nx], pv[nx]);
+        __syncthreads();
       }
     }
     // C layout: column (candidate) = lane & 31, row (query) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
