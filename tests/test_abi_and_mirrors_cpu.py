@@ -31,6 +31,18 @@ def test_library_exports_every_declared_symbol():
     assert L.mmf_version() == 3
 
 
+def test_abi_version_is_the_same_everywhere():
+    """include/mmf_hg.h, the built library, the ctypes binding and the build check of __graft_entry__ agree (a stale number in
+    any of them fails the driver's build step or the first load)."""
+    import re
+    import multimodal_fusion_amd as mmf
+    hdr = open(os.path.join(ROOT, "include", "mmf_hg.h")).read()
+    declared = int(re.search(r"#define\s+MMF_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert declared == mmf._lib.ABI_VERSION == mmf._lib.lib().mmf_version()
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "mmf_version() == mmf._lib.ABI_VERSION" in entry       # no literal version number to go stale there
+
+
 def test_abi_has_no_cpu_path():
     import ctypes
     import multimodal_fusion_amd as mmf
