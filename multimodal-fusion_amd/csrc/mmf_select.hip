@@ -39,6 +39,7 @@ struct SelectArgs {
   uint32_t* key_in; uint32_t* row_in;              // pass 0 writes
   const uint32_t* key_sorted; const uint32_t* row_sorted;   // pass 1 reads
   uint8_t* done;                                   // [n_rows] rows the grouped re-rank (rerank_group_kernel) has finished
+  uint8_t* late;                                   // [n_rows] rows the first pass handed on to the second (heavy after pruning), or nullptr
   int group_by_pos;                                // grouped re-rank: groups are 32 consecutive list positions (the scan took its queries with
                                                    //   near-duplicate rows next to each other: is_perm) instead of 32 rows of the key order
   int only_if;                                     // second pass: 0 always; 1 / 2: only when the grouped kernel finished less / not less than half of the waiting rows
@@ -88,12 +89,15 @@ __device__ __forceinline__ float chain_rows(const void* X, int64_t xr, const voi
   return acc;
 }
 
-// Gather the row's candidate ids from its lists into LDS.  Lists of the 16-bit scan carry the approximate
-// keys G of their entries, and each list was filled against the threshold of ITS columns only.  With several
-// lists per row the union proves a stronger one: if t is the (k + self)-th largest G over all lists, every
-// member of the final top-k has G >= t - margin(row) (same argument as inside the scan), so everything below
-// is dropped here, before any exact chain is spent on it.  (+16 in the ordered-int domain: stored keys carry
-// 4 slot bits.)  key[] is scratch for the approximate keys.  Returns -1 when the candidates do not fit.
+// Does the row wait for the second pass (room for many candidates; grouped re-rank)?  When it has overflow entries — or when the first
+// pass found it heavy: with many lists per row (paneled scans: a pair per panel) a cluster of near-duplicates fits the LISTS (18 lists hold
+// 270 entries), the row has no overflow entry although it carries a hundred candidates after pruning, and the first pass hands it on
+// (`late`; before pruning every row of a paneled scan looks heavy, so the raw counts cannot decide).
+__device__ __forceinline__ bool row_waits(const SelectArgs& a, int64_t pos) {
+  if (a.overflow[pos] != 0) return false;
+  return a.spill_cnt[pos] != 0 || (a.late != nullptr && a.late[pos] != 0);
+}
+
 __device__ __forceinline__ int gather_candidates(const SelectArgs& a, int64_t pos, int lane, uint32_t* id, float* key,
                                                  int maxc) {
   int total = 0;
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(256) void select_keys_kernel(SelectArgs a) {
   const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
   const int64_t mine = r0 + lane;
   bool deferred = false;
-  if (mine < a.n_rows) deferred = a.overflow[mine] == 0 && a.spill_cnt[mine] != 0;
+  if (mine < a.n_rows) deferred = row_waits(a, mine);
   unsigned long long todo = __ballot(deferred);
   uint32_t key = 0xffffffffu;
   const int nwait = __popcll(todo);
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
       // two passes: rows with overflow entries wait for the second launch, which has LDS room for them.  Both launches
       // cover every row and a row decides by its own counters which one it belongs to (a queue filled through one
       // atomic counter cost 25 cycles per row at the L2 when every row has overflow entries, i.e. on clustered data).
-      const bool deferred = a.overflow[pos] == 0 && a.spill_cnt[pos] != 0;
+      const bool deferred = row_waits(a, pos);
       if (deferred != (a.pass == 1)) continue;
       if (SECOND && a.pass == 1 && a.done && a.done[pos]) continue;
     }
@@ -406,6 +410,10 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
   if (!failed) {
     total = gather_candidates(a, pos, lane, id, key, maxc);
     if (total < 0) { failed = true; total = 0; }
+  }
+  if (!SECOND && a.two_pass && a.late && !failed && total > 2 * (a.k + a.exclude_self) + 32) {    // heavy after pruning: the second pass (grouped re-rank) takes it
+    if (lane == 0) a.late[pos] = 1;
+    continue;
   }
   const int64_t grow = a.row_offset + row;
   int valid = 0;
@@ -550,6 +558,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_staged_kernel(SelectArg
 // the lists could not serve) is left to the per-row pass behind this kernel (a.done stays 0).
 // ------------------------------------------------------------------------------------------------
 constexpr int GR_Q = 32, GR_PMAX = 512, GR_KC = 16, GR_MAXC = 224, GR_HASH = 1024, GR_LD = GR_KC + 1, GR_W = 8, GR_AHEAD = 8;
+static_assert(GR_Q * (GR_PMAX + 1) >= GR_W * 2 * SEL_MAXC, "the dots' LDS doubles as the waves' gather scratch");
 struct GroupLds {
   uint32_t cid[GR_Q][GR_MAXC];
   float dots[GR_Q][GR_PMAX + 1];       // before the matrix-core phase its first GR_Q x GR_MAXC floats hold the lists' approximate keys (gather_candidates' pruning)
@@ -582,7 +591,7 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
     const int64_t slot = slot0 + tid;
     int p = -1;
     if (slot < a.n_rows) {
-      if (a.group_by_pos) { if (a.overflow[slot] == 0 && a.spill_cnt[slot] != 0) p = (int)slot; }
+      if (a.group_by_pos) { if (row_waits(a, slot)) p = (int)slot; }
       else if (a.key_sorted[slot] != 0xffffffffu) p = (int)a.row_sorted[slot];
     }
     L.qpos[tid] = p;
@@ -624,7 +633,24 @@ __global__ __launch_bounds__(64 * GR_W) void rerank_group_kernel(SelectArgs a) {
     const int pos = L.qpos[q];
     if (pos < 0) continue;
     int total = -1;
-    if (a.overflow[pos] == 0) total = gather_candidates(a, pos, lane, L.cid[q], &L.dots[0][0] + q * GR_MAXC, GR_MAXC);
+    if (a.overflow[pos] == 0) {
+      if (a.lists * a.cap + a.spill_cap <= GR_MAXC) {
+        total = gather_candidates(a, pos, lane, L.cid[q], &L.dots[0][0] + q * GR_MAXC, GR_MAXC);
+      } else {
+        // many lists per row (paneled scans: one list pair per panel): the RAW entries can exceed what a row keeps here although the
+        // pruned set does not — gather and prune in this wave's 1024-entry scratch (the dots' LDS, idle until the matrix-core phase),
+        // then keep the result if it fits
+        uint32_t* sid = reinterpret_cast<uint32_t*>(&L.dots[0][0]) + w * (2 * SEL_MAXC);
+        float* skey = reinterpret_cast<float*>(sid + SEL_MAXC);
+        total = gather_candidates(a, pos, lane, sid, skey, SEL_MAXC);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        if (total > GR_MAXC) total = -1;
+        for (int e = lane; e < total; e += 64) L.cid[q][e] = sid[e];
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
     if (lane == 0) L.qtot[q] = total;
   }
   __syncthreads();
@@ -870,7 +896,7 @@ static int launch_select_m(const SelectArgs& a, bool vec4, bool staged16, void* 
         g = (grid + 7) / 8 * 8;
         b.order_blocks = g;
         // grouped re-rank of 32 consecutive rows of that order on the matrix cores; what it leaves is done by the launch below
-        if (a.done && (vec4 || staged16) && a.lists * a.cap + a.spill_cap <= GR_MAXC && !getenv("MMF_SELECT_NO_GROUPS")) {
+        if (a.done && (vec4 || staged16) && !getenv("MMF_SELECT_NO_GROUPS")) {
           MMF_HIP(hipMemsetAsync(a.done, 0, (size_t)a.n_rows, s));
           auto gk = a.dtype == MMF_F32 ? rerank_group_kernel<METRIC, MMF_F32>
                     : (a.dtype == MMF_BF16 ? rerank_group_kernel<METRIC, MMF_BF16> : rerank_group_kernel<METRIC, MMF_F16>);
@@ -944,6 +970,8 @@ int launch_select(const SelectProblem& p, const CandLists& L, hipStream_t s) {
     const size_t nn = ((size_t)p.n_rows + 63) & ~size_t(63);
     a.key_in = o; a.row_in = o + nn; a.key_sorted = o + 2 * nn; a.row_sorted = o + 3 * nn;
     a.done = reinterpret_cast<uint8_t*>(o + 4 * nn);
+    a.late = a.done + nn;                            // (the block is nn words: done takes its first n bytes, late the n bytes from nn on)
+    MMF_HIP(hipMemsetAsync(a.late, 0, (size_t)p.n_rows, s));
     a.defer_cnt = o + 5 * nn;
     order_temp = o + 5 * nn + 512;
     order_temp_bytes = select_order_bytes(p.n_rows) - (5 * nn + 512) * 4;

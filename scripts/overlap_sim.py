@@ -18,7 +18,9 @@ if OCC_WGS:
     occ.occupy_launch.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
     sink = torch.zeros(4, device='cuda')
     occ_stream = torch.cuda.Stream()
-Y = make_rows(0, N, d, dev)
+import os
+DATA = os.environ.get("DATA", "gaussian")          # DATA=clustered: the bench's near-duplicate workload
+Y = make_rows(0, N, d, dev, data=DATA)
 ref_i, ref_v = mmf.simtopk(Y, metric='cosine', k=5)
 
 class FakeWork:
@@ -53,6 +55,7 @@ for P in ((8,) if OCC_WGS else (2, 4, 8)):
         else:
             t.copy_(store[key])
     dmod._gather_into, dmod._gather_event, dmod._allreduce_max = gather, gather_event, armax
+    dmod.dist.get_rank = lambda group=None: mode["rank"]        # the driver asks which rank it is (own rows first)
     import torch.distributed as dist
     for r in range(P):
         mode["rank"] = r; calls["i"] = 0
@@ -66,6 +69,7 @@ for P in ((8,) if OCC_WGS else (2, 4, 8)):
         if isinstance(store[key], dict):
             store[key] = torch.cat([store[key][r].reshape(1, -1) for r in range(P)], 0)
     mode["record"] = False
+    mode["rank"] = rank
     xl = Y[lo:hi].contiguous()
     for it in range(6):
         calls["i"] = 0
@@ -77,5 +81,5 @@ for P in ((8,) if OCC_WGS else (2, 4, 8)):
         t1 = time.perf_counter()
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
     ok = torch.equal(i, ref_i[lo:hi]) and torch.equal(v, ref_v[lo:hi])
-    print("chunks=%d occ=%dx%.1fms front=%s " % (CH, OCC_WGS, OCC_MS, __import__("os").environ.get("MMF_PANEL_FRONT_FACTOR", "2")) + "P=%d rank=%d rows=%d: wall=%.2f ms (host enqueue %.2f) scan=%.2f prep=%.2f rerank=%.2f fb=%d (overflow %d short %d) cand/row=%.1f parity=%s" % (
+    print(DATA + " chunks=%d occ=%dx%.1fms front=%s " % (CH, OCC_WGS, OCC_MS, __import__("os").environ.get("MMF_PANEL_FRONT_FACTOR", "2")) + "P=%d rank=%d rows=%d: wall=%.2f ms (host enqueue %.2f) scan=%.2f prep=%.2f rerank=%.2f fb=%d (overflow %d short %d) cand/row=%.1f parity=%s" % (
         P, rank, hi - lo, dt, (t1 - t0) * 1e3, st['scan_ms'], st['prep_ms'], st['rerank_ms'], st['fallback_rows'], st['overflow_rows'], st['short_rows'], st['candidates'] / (hi - lo), ok), flush=True)
