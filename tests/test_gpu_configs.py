@@ -190,6 +190,8 @@ def test_paneled_scan_equals_single_call(mmf, metric, S, splits):
     X = make(N, d, 41) * (1.0 if metric == "cosine" else (0.05 if metric == "rbf" else 3.0))
     X[300:360] = X[300]                       # 60 exact copies: their columns overflow the lane lists into the rows'
     X[5000:5060] = X[300]                     # overflow lists, whose ids go through the panel -> global column map
+    X[7000:7050] = X[7000]                    # 50 copies: they FIT the many lists of a paneled scan (no overflow entry), but each of these
+                                              # rows carries 49 candidates after pruning: the first re-rank pass hands them to the second
     full_i, full_v = mmf.simtopk(X, metric=metric, lam=0.5, k=k)
     ex_i, _ = mmf.simtopk(X, metric=metric, lam=0.5, k=k, precision="exact")
     assert torch.equal(full_i, ex_i)
