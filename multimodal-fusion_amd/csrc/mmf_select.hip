@@ -117,15 +117,21 @@ __device__ __forceinline__ int gather_candidates(const SelectArgs& a, int64_t po
     if (raw > maxc) return -1;
     const uint32_t excl = incl - mycn;
     const int g = lane >> 4, e = lane & 15;
+    // (loads unconditional — a clamped address where the lane has no entry — and four steps unrolled: the loads of a step do not wait
+    //  for the LDS writes of the one before)
+#pragma unroll 4
     for (int l0 = 0; l0 < a.lists; l0 += 4) {
       const int l = l0 + g;
       const int src = l < a.lists ? l : 0;
       const uint32_t cn = (uint32_t)__shfl((int)mycn, src);
       const uint32_t off = (uint32_t)__shfl((int)excl, src);
-      if (l < a.lists && (uint32_t)e < cn) {
-        const int64_t at = (pos * a.lists + l) * a.cap + e;
-        id[off + e] = a.cand_ids[at];
-        if (prune) key[off + e] = a.cand_keys[at];
+      const bool mine = l < a.lists && (uint32_t)e < cn;
+      const int64_t at = mine ? (pos * a.lists + l) * a.cap + e : pos * a.lists * a.cap;
+      const uint32_t vi = a.cand_ids[at];
+      const float vk = prune ? a.cand_keys[at] : 0.0f;
+      if (mine) {
+        id[off + e] = vi;
+        if (prune) key[off + e] = vk;
       }
     }
     total = raw;
